@@ -1,0 +1,273 @@
+/* libtavhip — C ABI of the MI355X-native TAV (text+audio+video) fusion forward/backward hot path.
+ *
+ * The reference (g8a9/multi-modal-emotion) has no native/FFI layer: the hot path is the ATen op call-sites of
+ *   models/tav.py:344-504 (PreFormer.forward, TAVForMAE.forward), utils/TAVFormer.py:10-439 (fusion encoders) and the
+ *   Hugging Face modules they call (roberta/bert, wav2vec2, videomae), driven by train_model/tav_train.py:15-65.
+ * Each entry point below is the operator a binding for that path would need, and cites the call-site it replaces.
+ *
+ * Rules of the ABI
+ *   - extern "C", plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise.
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it (no allocation, no synchronisation,
+ *     safe under hipGraph capture).  Workspaces are supplied by the caller.
+ *   - return 0 on success, a negative TAV_ERR_* for a rejected argument (nothing was launched), or a positive
+ *     hipError_t from the launch.  The Python host layer turns any non-zero value into RuntimeError.
+ *   - dtype codes: TAV_F32 (exact-f32 parity path, f32-input MFMA) and TAV_BF16 (bf16 operands, f32 accumulate).
+ *     Residual streams, LayerNorm statistics, softmax statistics, losses and all parameter gradients are f32.
+ *   - matrices are row-major "token-major": [tokens, features]; ld* are row strides in ELEMENTS.
+ */
+#ifndef TAVHIP_H
+#define TAVHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TAV_F32 = 0, TAV_BF16 = 1 };
+enum {
+    TAV_ERR_NULL = -1,  /* required pointer missing           */
+    TAV_ERR_SHAPE = -2, /* size not supported by the kernel   */
+    TAV_ERR_DTYPE = -3, /* dtype code / combination rejected  */
+    TAV_ERR_ALIGN = -4  /* stride or offset breaks 16-B access */
+};
+
+int tav_version(void);                 /* ABI version, bumped on any signature change */
+const char* tav_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GEMM, "NT": C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][n][k] )
+ *   epi(v): v += bias[n]; if C_pre: C_pre = v; if act==1: v = gelu_erf(v); if gelu_in: v *= gelu'(gelu_in[m][n]);
+ *           if resid: v += resid[m][n] (f32); if accumulate: v += C[m][n]; C = v.
+ * Replaces nn.functional.linear / nn.Linear on the path (utils/TAVFormer.py:348-350,401-403,419,432; HF linears),
+ * their input-gradients (with B = W^T), nn.Conv1d of the wav2vec2 feature encoder (A rows overlap: lda = stride*C_in,
+ * K = k*C_in, z = batch) and the grouped positional conv (z = batch x group).
+ * z = zb * nzg + zg; A/C offsets use both zb and zg strides, B/bias are offset per zg (and zb if b_zb != 0).
+ * Constraints: K*sizeof(in) % 128 == 0, N % 4 == 0, strides multiples of 16 bytes.  in f32 => out f32. */
+typedef struct tav_gemm_nt_args {
+    const void* A; const void* B; void* C;
+    void* C_pre;            /* optional, dtype/layout of C                               */
+    const float* bias;      /* optional [N] f32                                          */
+    const void* gelu_in;    /* optional, dtype of A, layout of C (ld_gelu_in)            */
+    const float* resid;     /* optional f32, layout of C (ld_resid)                      */
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ld_pre, ld_gelu_in, ld_resid;
+    int32_t nzb, nzg;       /* 0 is read as 1 */
+    int64_t a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg;
+    int32_t in_dtype, out_dtype;
+    int32_t act;            /* 0 none, 1 exact-erf GELU */
+    int32_t accumulate;
+    float alpha;
+} tav_gemm_nt_args;
+int tav_gemm_nt(const tav_gemm_nt_args* args, void* stream);
+
+/* GEMM, "TN" (weight gradients): out[n1][perm(n2)] (+)= scale * sum_{z,t} A[z][t][n1] * B[z][t][n2].
+ * The token axis is split into `nsplit` chunks that write f32 slabs [nsplit][N1][N2]; a second kernel sums the slabs
+ * in a fixed order (bitwise reproducible; no atomics).  perm(n2) = (n2 % perm_inner)*perm_outer + n2/perm_inner maps
+ * the [k][c_in] column order of the conv-as-GEMM back to nn.Conv1d's [c_in][k]; perm_outer <= 1 means identity.
+ * Replaces the autograd weight-gradient of every nn.Linear / nn.Conv1d on the path (train_model/tav_train.py:60).
+ * tav_gemm_tn_splits() (host-only) returns the chunking the library wants for a shape. */
+typedef struct tav_gemm_tn_args {
+    const void* A; const void* B;
+    float* slabs;           /* workspace, nsplit*N1*N2 f32 */
+    float* out;             /* [N1][N2] f32 */
+    int64_t N1, N2;
+    int64_t lda, ldb;
+    int64_t rows_per_batch, nbatch;
+    int64_t a_zb, b_zb;
+    int32_t chunk_rows, nsplit;
+    int32_t perm_inner, perm_outer;
+    int32_t dtype;
+    int32_t accumulate;
+    float scale;            /* 0 is read as 1 */
+} tav_gemm_tn_args;
+int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit);
+int tav_gemm_tn(const tav_gemm_tn_args* args, void* stream);
+
+/* Column sums (bias gradients): out[n] (+)= sum_m x[m][n]; partials = workspace nparts*N f32. */
+int tav_colsum(const void* x, int32_t dtype, int64_t M, int64_t N, int64_t ld, float* partials, int32_t nparts, float* out,
+               int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused multi-head self-attention, head_dim 64, flash-style (no S x S buffer).
+ * q/k/v/o/do/dq/dk/dv are token-major with arbitrary row stride (e.g. slices of a fused [tokens, 3H] buffer):
+ *   element (b, s, head, d) at ptr[(b*S + s)*ld + head*64 + d].
+ * mask_mode 0: none                                  (HF videomae/wav2vec2 attention, no mask on the path)
+ *           1: scores += key_mask[b][key] BEFORE softmax (HF roberta/bert additive mask; utils/TAVFormer.py:68-72)
+ *           2: probs  += key_mask[b][key] AFTER  softmax (the fusion encoder's quirk, utils/TAVFormer.py:362-383):
+ *              o = softmax(s) v + (sum_key mask[key] v[key]) for every query row; `corr` [B][nheads][64] f32 receives
+ *              that rank-1 term (needed again by the backward).
+ * scale is applied to q.k^T (1/8 on the path).  lse [B][nheads][S] f32 = log-sum-exp of the scaled (masked) scores.
+ * Replaces utils/TAVFormer.py:357-383, :57-81 and HF eager_attention_forward. */
+typedef struct tav_attn_args {
+    const void* q; const void* k; const void* v;
+    void* o;
+    const float* key_mask;  /* [B][S] f32 or NULL */
+    float* lse;             /* [B][nheads][S]     */
+    float* corr;            /* [B][nheads][64], mask_mode 2 only */
+    /* backward only */
+    const void* dout; void* dq; void* dk; void* dv;
+    float* delta;           /* workspace [B][nheads][S] f32 */
+    int64_t B, S, nheads;
+    int64_t ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
+    int32_t dtype, mask_mode;
+    float scale;
+} tav_attn_args;
+int tav_attn_fwd(const tav_attn_args* args, void* stream);
+int tav_attn_bwd(const tav_attn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last axis (width W <= 1024, W % 4 == 0), one wave per row, f32 statistics.
+ * fwd: y = (x - mean) * rstd * gamma + beta; writes y_f32 and/or y_lp (low-precision copy in `lp_dtype`, the next
+ *      GEMM's operand) and mean/rstd [rows] f32.
+ * bwd: dx = rstd*(dy*gamma - mean(dy*gamma) - xhat*mean(dy*gamma*xhat)) (+ dx_add); writes dx_f32 and/or dx_lp;
+ *      dgamma/dbeta (+)= column sums (two deterministic stages through `partials`, >= tav_ln_bwd_partials(rows)*2*W f32).
+ * Replaces nn.LayerNorm on the path (utils/TAVFormer.py:237,239,108,118; models/tav.py:439-447; HF LN sites). */
+typedef struct tav_ln_args {
+    const void* x; int32_t x_dtype;
+    const float* gamma; const float* beta;
+    float* y_f32; void* y_lp; int32_t lp_dtype;
+    float* mean; float* rstd;
+    /* backward */
+    const void* dy; int32_t dy_dtype;
+    const float* dx_add;    /* optional f32 [rows][W] added to dx */
+    float* dx_f32; void* dx_lp;
+    float* dgamma; float* dbeta; float* partials; int32_t accumulate_params;
+    int64_t rows, W;
+    int64_t ld_x, ld_y, ld_dy, ld_dx;
+    float eps;
+    int32_t act;            /* 1: y = gelu_erf(layernorm(x)) (wav2vec2 "layer" conv blocks, HF wav2vec2:275-301); bwd needs beta */
+} tav_ln_args;
+int tav_ln_fwd(const tav_ln_args* args, void* stream);
+int tav_ln_bwd(const tav_ln_args* args, void* stream);
+int tav_ln_bwd_partials(int64_t rows);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Element-wise / data-movement kernels (all HBM-bound). */
+
+/* dst = cast(src) ; optionally also dst_t[c][r] = cast(src[r][c]) (the W^T copy used by dgrad). src f32 [R][C]. */
+int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
+/* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst) and its dgrad form [k*ci... see DESIGN.md] */
+int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
+/* generic strided cast/copy: dst[r][c] = src[r][c] for r<R, c<C (dtypes may differ) */
+int tav_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst, int64_t R, int64_t C,
+               void* stream);
+/* y_f32 = a + b (f32) and optional low-precision copy */
+int tav_add_f32(const float* a, const float* b, float* y, void* y_lp, int32_t lp_dtype, int64_t n, void* stream);
+/* fill f32 */
+int tav_fill_f32(float* p, float value, int64_t n, void* stream);
+
+/* out[b][s][:] = x[b][s][:] + table[ids[b][s]][:]   (models/tav.py:474, nn.Embedding(3,768) add); x,out f32 */
+int tav_embed_add_fwd(const float* x, const int64_t* ids, const float* table, float* out, int64_t rows, int64_t W, int64_t ntable,
+                      void* stream);
+/* dtable[t][:] (+)= sum_{rows with ids==t} dy[row][:]  (ntable <= 8; deterministic) */
+int tav_embed_add_bwd(const float* dy, const int64_t* ids, float* dtable, float* partials, int64_t rows, int64_t W, int64_t ntable,
+                      int32_t accumulate, void* stream);
+int tav_embed_add_bwd_parts(int64_t rows);   /* partials = parts * ntable * W f32 */
+
+/* BERT/RoBERTa embeddings (HF roberta/modeling_roberta.py:75-121): e = word[ids] + pos[pos_ids] + type[0], then LayerNorm.
+ * pos_ids computed on device: roberta: cumsum(ids != pad)*(ids != pad) + pad ; bert (pad_id < 0): arange(S).
+ * Outputs LN result as f32 and/or lp copy; saves mean/rstd and the pre-LN sum (pre, f32) for the backward. */
+typedef struct tav_text_embed_args {
+    const int64_t* ids;     /* [B][S] */
+    const float* word; const float* pos; const float* type;   /* tables f32 */
+    const float* gamma; const float* beta;
+    float* pre;             /* [B*S][W] f32 pre-LayerNorm sum   */
+    int64_t* pos_ids;       /* [B][S] out                       */
+    float* y_f32; void* y_lp; int32_t lp_dtype;
+    float* mean; float* rstd;
+    int64_t B, S, W, vocab, max_pos;
+    int32_t pad_id;         /* >= 0: RoBERTa position ids; < 0: BERT */
+    float eps;
+} tav_text_embed_args;
+int tav_text_embed_fwd(const tav_text_embed_args* args, void* stream);
+/* scatter-add of row gradients into a table: dtable[idx[r]][:] += d[r][:] (f32 atomics; table zeroed by caller) */
+int tav_scatter_add_rows(const float* d, const int64_t* idx, float* dtable, int64_t rows, int64_t W, int64_t ntable, void* stream);
+
+/* VideoMAE tubelet patch gather (HF videomae/modeling_videomae.py:157-177 Conv3d k=s=(2,16,16) as a GEMM A operand):
+ * video f32 [B][F][3][H][W] (frames-first, models/tav.py:243) -> patches [B*nkeep][3*2*16*16] in `dtype`,
+ * only for the token indices keep_idx[B][nkeep] (int32, ascending = the rows `embeddings[~mask]` keeps). */
+int tav_patchify(const float* video, const int32_t* keep_idx, void* patches, int32_t dtype, int64_t B, int64_t F, int64_t H, int64_t W,
+                 int64_t nkeep, void* stream);
+/* per row of mask [B][n] (uint8/bool; keep where mask == keep_value): write ascending indices [B][nkeep];
+ * counts[B] receives the number found (host checks == nkeep when it wants to). */
+int tav_mask_to_index(const uint8_t* mask, int32_t keep_value, int32_t* keep_idx, int32_t* counts, int64_t B, int64_t n, int64_t nkeep,
+                      void* stream);
+/* out[r][:] = table[idx[r]][:] f32 -- rows of the fixed sin-cos position table (HF videomae:80-124) for the kept tokens;
+ * the result is handed to the patch-embedding GEMM as its `resid` so the add is fused. */
+int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, void* stream);
+
+/* mean over tokens: y[b][:] = mean_s x[b][s][:] (models/tav.py:478,481,488) and its backward dx[b][s][:] = dy[b][:]/S */
+int tav_mean_pool_fwd(const float* x, float* y, int64_t B, int64_t S, int64_t W, void* stream);
+int tav_mean_pool_bwd(const float* dy, float* dx, void* dx_lp, int32_t lp_dtype, int64_t B, int64_t S, int64_t W, void* stream);
+
+/* small dense head (N <= 16, e.g. Linear(3072,7), models/tav.py:499): y = x W^T + b ; all f32.
+ * bwd: dx = dy W ; dW (+)= dy^T x ; db (+)= colsum(dy) */
+int tav_head_fwd(const float* x, const float* W, const float* b, float* y, int64_t B, int64_t K, int64_t N, void* stream);
+int tav_head_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t B, int64_t K, int64_t N,
+                 int32_t accumulate, void* stream);
+/* tanh pooler epilogue (HF roberta:530-536): y = tanh(x) and dx = dy*(1-y^2) */
+int tav_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int tav_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+
+/* (weighted) cross entropy, mean reduction (utils/global_functions.py:63-64,76,83; torch.nn.CrossEntropyLoss):
+ * loss = sum_i w[t_i] * (lse_i - z_i[t_i]) / sum_i w[t_i];  dlogits written in the same pass (scaled by grad_scale). */
+int tav_cross_entropy(const float* logits, const int64_t* target, const float* class_weight /*opt*/, float* loss, float* dlogits,
+                      int64_t B, int64_t C, float grad_scale, void* stream);
+
+/* dropout with a counter-based RNG (models/tav.py:497-498): y = x * keep / (1-p); mask bytes saved for backward */
+int tav_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+int tav_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+
+/* wav2vec2 feature encoder pieces (HF wav2vec2/modeling_wav2vec2.py:275-323,382-419) -- activations are kept
+ * channels-last [B][T][C] so every later conv is a GEMM over overlapping rows.
+ * conv0: Conv1d(1, C, k=10, s=5) direct: y[b][t][c] = sum_j x[b][5t+j] w[c][j] (+ bias[c]) */
+int tav_conv0_fwd(const float* wave, const float* w, const float* bias, void* y, int32_t y_dtype, int64_t B, int64_t T_in, int64_t T_out,
+                  int64_t C, int64_t K, int64_t stride, void* stream);
+int tav_conv0_bwd_w(const float* wave, const void* dy, int32_t dy_dtype, float* dw, float* dbias, float* partials, int64_t B, int64_t T_in,
+                    int64_t T_out, int64_t C, int64_t K, int64_t stride, int32_t accumulate, void* stream);
+int tav_conv0_bwd_partials(int64_t B, int64_t T_out, int64_t C, int64_t K);   /* floats */
+/* GroupNorm(num_groups == channels) over time, then GELU: y = gelu((x - mean_bc) * rstd_bc * gamma_c + beta_c).
+ * stats [B][C][2] f32 (mean, rstd).  bwd returns dx and dgamma/dbeta. */
+int tav_gn_workspace_floats(int64_t B, int64_t C);
+int tav_gn_gelu_fwd(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta, float* stats, float* workspace, int64_t B,
+                    int64_t T, int64_t C, float eps, void* stream);
+int tav_gn_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, const float* gamma, const float* beta, const float* stats,
+                    float* workspace, float* dgamma, float* dbeta, int64_t B, int64_t T, int64_t C, int32_t accumulate, void* stream);
+/* y = gelu(x) and dx = dy * gelu'(x) for tensors in `dtype` */
+int tav_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream);
+int tav_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream);
+/* col2im for the strided convs' input gradient: dcol [B][T_out][k*C] (the dgrad GEMM's output) -> dx [B][T_in][C],
+ * dx[b][tau][:] = sum_{j : (tau-j) % s == 0, 0 <= (tau-j)/s < T_out} dcol[b][(tau-j)/s][j*C + :] ; optional fused
+ * multiply by gelu'(pre[b][tau][:]) of the producing layer. */
+int tav_col2im_1d(const void* dcol, void* dx, const void* pre_act, int32_t dtype, int64_t B, int64_t T_in, int64_t T_out, int64_t C,
+                  int64_t K, int64_t stride, void* stream);
+/* grouped positional conv support (HF wav2vec2:326-379): zero-padded, group-major copy
+ * xg[b][g][pad_l + t][cg] = x[b][t][g*Cg + cg]; rows outside [0,T) are zero.  Inverse (add) for the gradient. */
+int tav_group_pad(const void* x, int32_t x_dtype, void* xg, int32_t xg_dtype, int64_t B, int64_t T, int64_t H, int64_t G, int64_t pad_l,
+                  int64_t pad_r, void* stream);
+/* weight-norm reparametrisation w = g * v / ||v||  with the norm over (co, ci) per tap k (weight_norm dim=2):
+ * v [H][Cg][K] f32, g [K] f32 -> w (GEMM layout [G][Cg_out][K][Cg_in] in `dtype`, and its flipped dgrad form);
+ * norms [K] f32 saved.  bwd: dv, dg from dw (dw in the GEMM layout, f32). */
+int tav_weight_norm_partials(int64_t H, int64_t Cg);   /* fwd partials = this * K floats */
+int tav_weight_norm_fwd(const float* v, const float* g, float* norms, float* partials, void* w, void* w_flip, int32_t dtype, int64_t H,
+                        int64_t Cg, int64_t K, void* stream);
+/* workspace floats: H*Cg*K + tav_weight_norm_partials(H,Cg)*K + K */
+int tav_weight_norm_bwd(const float* v, const float* g, const float* norms, const float* dw_gemm, float* workspace, float* dv, float* dg,
+                        int64_t H, int64_t Cg, int64_t K, int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Optimiser-side kernels (train_model/tav_train.py:61-62,148): multi-tensor via device pointer tables.
+ * ptrs/sizes are device arrays of `ntensors` entries. */
+int tav_sumsq_partials(int32_t ntensors);   /* floats of workspace */
+int tav_sumsq_multi(const float* const* ptrs, const int64_t* sizes, int32_t ntensors, float* partials, float* out_sumsq, void* stream);
+/* p -= lr*(m_hat/(sqrt(v_hat)+eps)) after p *= (1-lr*wd); grads scaled by *clip_coef_ptr (device scalar, computed by
+ * tav_clip_coef from the global norm) so no host sync is needed between norm and step. */
+int tav_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
+int tav_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                    int32_t ntensors, const float* clip_coef /*opt*/, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAVHIP_H */

@@ -1,0 +1,627 @@
+// Fused multi-head self-attention (head_dim 64), forward and backward, flash-style: the S x S score matrix never
+// exists in memory.  Replaces reference utils/TAVFormer.py:357-383 (fusion encoder, mask added AFTER softmax),
+// utils/TAVFormer.py:57-81 (TransformerEncoder, mask before softmax) and HF eager_attention_forward
+// (roberta/bert with additive key mask, wav2vec2 / videomae without mask).
+//
+// Orientation.  Scores are produced TRANSPOSED, S^T[key][query] = K . Q^T, with the key index in the accumulator
+// registers (rows 4g+r of a 16x16 tile) and the query on the lane.  The softmax reduction over keys is then in-lane
+// plus two cross-lane steps (xor 16, 32), and P^T is already laid out as the k-strided operand of
+// O^T[d][query] += V^T[d][key] . P^T[key][query]  (common.h: acc_to_kfrag), whose other operand is read from the
+// natural [key][d] LDS image of V with ds_read_b64_tr_b16 (bf16) / ds_read_b32 (f32).  No P round-trip through LDS.
+//
+// Backward is two deterministic kernels (no atomics):
+//   dkdv: one workgroup per 128 keys, S[query][key] with the key on the lane -> P and dS feed dV^T += dO^T P and
+//         dK^T += Q^T dS directly;   dq: one workgroup per 128 queries, S^T/dP^T as in the forward -> dQ^T += K^T dS^T.
+//
+// Mask modes: 0 none; 1 additive key mask before softmax; 2 additive key mask AFTER softmax (the reference quirk):
+//   o_q = softmax(s_q) V + c,  c = sum_key mask[key] v[key]   (rank-1, same for every query of a (batch, head)),
+//   backward: dV[key] += mask[key] * sum_q dO_q  and  delta_q = dO_q . (o_q - c).
+#include "common.h"
+#include "tavhip_internal.h"
+
+namespace tav {
+
+struct AttnP {
+    const char* q; const char* k; const char* v; char* o;
+    const float* mask; float* lse; float* corr;
+    const char* dout; char* dq; char* dk; char* dv; float* delta;
+    int B, S, nh;
+    long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
+    float scale;
+};
+
+template <typename T> struct HD {
+    static constexpr int ES = ET<T>::ES;
+    static constexpr int ROWB = 64 * ES;            // bytes per head row
+    static constexpr int ROWCH = ROWB / 16;         // 16-byte chunks per row (8 / 16)
+    static constexpr int NSD = ROWCH / 4;           // mma16 steps over d (2 / 4)
+    static constexpr int PITCH_N = ROWB + (ES == 2 ? 32 : 16);   // natural image pitch (k-strided reads conflict-free)
+    // row image: chunk index XOR-swizzled so ds_read_b128 of (16 rows x 1 chunk) per lane group is conflict-free
+    static TAV_DEV int row_off(int row, int chunk) {
+        return row * ROWB + ((chunk ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15))) << 4);
+    }
+};
+
+// Stage ROWS x 64 elements of one head (rows row0.., clamped/zero-filled past S) into registers.
+template <typename T, int ROWS, bool ZERO_PAD>
+TAV_DEV void tile_gload(uint4* regs, const char* base, long ld_bytes, int row0, int S, int tid) {
+    constexpr int ROWCH = HD<T>::ROWCH, N = ROWS * ROWCH / 256;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int idx = tid + 256 * e, row = idx / ROWCH, ch = idx - row * ROWCH;
+        int r = row0 + row;
+        const bool ok = r < S;
+        if (!ok) r = S - 1;
+        uint4 v = *reinterpret_cast<const uint4*>(base + (long)r * ld_bytes + ch * 16);
+        if (ZERO_PAD && !ok) v = make_uint4(0, 0, 0, 0);
+        regs[e] = v;
+    }
+}
+template <typename T, int ROWS>
+TAV_DEV void tile_lstore_row(const uint4* regs, char* img, int tid) {
+    constexpr int ROWCH = HD<T>::ROWCH, N = ROWS * ROWCH / 256;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int idx = tid + 256 * e, row = idx / ROWCH, ch = idx - row * ROWCH;
+        *reinterpret_cast<uint4*>(img + HD<T>::row_off(row, ch)) = regs[e];
+    }
+}
+template <typename T, int ROWS>
+TAV_DEV void tile_lstore_nat(const uint4* regs, char* img, int tid) {
+    constexpr int ROWCH = HD<T>::ROWCH, N = ROWS * ROWCH / 256;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int idx = tid + 256 * e, row = idx / ROWCH, ch = idx - row * ROWCH;
+        *reinterpret_cast<uint4*>(img + row * HD<T>::PITCH_N + ch * 16) = regs[e];
+    }
+}
+
+// lane (g,i) fragment of a row held in global memory: chunk 4s+g of row `r` (clamped)
+template <typename T>
+TAV_DEV void row_frags_gload(uint4* f, const char* base, long ld_bytes, int r, int S, int g) {
+    if (r >= S) r = S - 1;
+#pragma unroll
+    for (int s = 0; s < HD<T>::NSD; ++s) f[s] = *reinterpret_cast<const uint4*>(base + (long)r * ld_bytes + (4 * s + g) * 16);
+}
+
+// ================================================================================================= forward
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    using H = HD<T>;
+    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
+    constexpr int NCH = BKV * H::ROWCH / 256;
+    constexpr int KROW_B = BKV * H::ROWB, VNAT_B = BKV * H::PITCH_N;
+    constexpr int BUF_B = KROW_B + VNAT_B + 2 * BKV * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 2 * BUF_B);   // [4][64] + [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long hoff = (long)head * 64 * ES;
+    const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
+    const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
+    const char* Vb = p.v + (long)b * S * p.ld_v * ES + hoff;
+    const float* maskb = p.mask ? p.mask + (long)b * S : nullptr;
+
+    uint4 qf[2][NSD];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q0 + 16 * qt + i, S, g);
+
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    f32x4 oacc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { oacc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float corr_part = 0.f;
+
+    const int nkt = (S + BKV - 1) / BKV;
+    uint4 rk[NCH], rv[NCH];
+    float r_kadd = 0.f, r_cm = 0.f;
+    auto gload = [&](int t) {
+        tile_gload<T, BKV, false>(rk, Kb, p.ld_k * ES, t * BKV, S, tid);
+        tile_gload<T, BKV, false>(rv, Vb, p.ld_v * ES, t * BKV, S, tid);
+        if (tid < BKV) {
+            const int key = t * BKV + tid;
+            const bool ok = key < S;
+            const float mv = (MODE != 0 && ok) ? maskb[key] : 0.f;
+            r_kadd = ok ? (MODE == 1 ? mv : 0.f) : -INFINITY;
+            r_cm = (MODE == 2) ? mv : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF_B;
+        tile_lstore_row<T, BKV>(rk, base, tid);
+        tile_lstore_nat<T, BKV>(rv, base + KROW_B, tid);
+        if (tid < BKV) {
+            float* f = reinterpret_cast<float*>(base + KROW_B + VNAT_B);
+            f[tid] = r_kadd; f[BKV + tid] = r_cm;
+        }
+    };
+    gload(0); lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nkt) gload(t + 1);
+        const char* Krow = smem + cur * BUF_B;
+        const char* Vnat = Krow + KROW_B;
+        const float* kadd = reinterpret_cast<const float*>(Vnat + VNAT_B);
+        const float* cm = kadd + BKV;
+
+        f32x4 sacc[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { sacc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sacc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < NSD; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const uint4 a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
+                mma16<T>(a, qf[0][s], sacc[kt][0]);
+                mma16<T>(a, qf[1][s], sacc[kt][1]);
+            }
+        // scale + key additive (mask / validity), running max per query (= per lane i, both q tiles)
+        float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                sacc[kt][qt] = sacc[kt][qt] * p.scale + ka;
+                mx[qt] = fmaxf(mx[qt], fmaxf(fmaxf(sacc[kt][qt][0], sacc[kt][qt][1]), fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx[qt]);
+            const float alpha = __expf(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __expf(sacc[kt][qt][r] - m_new); sacc[kt][qt][r] = e; rs += e; }
+            l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int ks = 0; ks < BKV / KSTEP; ++ks) {
+            uint4 pb[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 tl[2];
+                tl[0] = sacc[ks * ET<T>::ACC_TILES][qt];
+                tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
+                pb[qt] = acc_to_kfrag<T>(tl);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                mma16<T>(a, pb[0], oacc[dt][0]);
+                mma16<T>(a, pb[1], oacc[dt][1]);
+            }
+        }
+        if (MODE == 2) {   // c[d] += sum_key mask[key] * V[key][d]; thread -> (d = tid & 63, 16 keys of this tile)
+            const int d = tid & 63, kq = tid >> 6;
+#pragma unroll 4
+            for (int kk = 0; kk < 16; ++kk) {
+                const int key = kq * 16 + kk;
+                corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
+            }
+        }
+        if (t + 1 < nkt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (MODE == 2) {
+        red[wave * 64 + lane] = corr_part;
+        __syncthreads();
+        if (tid < 64) {
+            const float c = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+            red[256 + tid] = c;
+            if (blockIdx.x == 0) p.corr[((long)b * p.nh + head) * 64 + tid] = c;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int q = q0 + 16 * qt + i;
+        if (q < S) {
+            const float inv = 1.f / l;
+            T* orow = reinterpret_cast<T*>(p.o) + ((long)b * S + q) * p.ld_o + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 v = oacc[dt][qt] * inv;
+                if (MODE == 2) v += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g);
+                st4(orow + 16 * dt + 4 * g, v);
+            }
+            if (g == 0) p.lse[((long)b * p.nh + head) * S + q] = m_run[qt] + __logf(l);
+        }
+    }
+}
+
+// ================================================================================================= backward: delta
+// delta[b][h][q] = sum_d dO[q][d] * (O[q][d] - corr[d])
+template <typename T, int MODE>
+__global__ void attn_bwd_delta_kernel(const AttnP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;            // over B*S*nh, head fastest
+    const long total = (long)p.B * p.S * p.nh;
+    if (row >= total) return;
+    const int head = (int)(row % p.nh);
+    const long bs = row / p.nh;
+    const int b = (int)(bs / p.S), s = (int)(bs - (long)b * p.S);
+    const float o = ET<T>::ld(reinterpret_cast<const T*>(p.o) + bs * p.ld_o + head * 64 + lane);
+    const float d_o = ET<T>::ld(reinterpret_cast<const T*>(p.dout) + bs * p.ld_do + head * 64 + lane);
+    float c = 0.f;
+    if (MODE == 2) c = p.corr[((long)b * p.nh + head) * 64 + lane];
+    const float v = wave_sum(d_o * (o - c));
+    if (lane == 0) p.delta[((long)b * p.nh + head) * p.S + s] = v;
+}
+
+// ================================================================================================= backward: dK, dV
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
+    using H = HD<T>;
+    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = 32;
+    constexpr int NCH = BQ * H::ROWCH / 256;
+    constexpr int ROW_B = BQ * H::ROWB, NAT_B = BQ * H::PITCH_N;
+    constexpr int BUF_B = 2 * ROW_B + 2 * NAT_B + 2 * BQ * 4;   // Qrow, dOrow, Qnat, dOnat, lse, delta
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 2 * BUF_B);   // [4][64] + [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const long hoff = (long)head * 64 * ES;
+    const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
+    const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
+    const char* Vb = p.v + (long)b * S * p.ld_v * ES + hoff;
+    const char* dOb = p.dout + (long)b * S * p.ld_do * ES + hoff;
+    const float* lseb = p.lse + ((long)b * p.nh + head) * S;
+    const float* deltab = p.delta + ((long)b * p.nh + head) * S;
+
+    uint4 kf[2][NSD], vf[2][NSD];
+    float kadd[2], cmk[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + 16 * kt + i;
+        row_frags_gload<T>(kf[kt], Kb, p.ld_k * ES, key, S, g);
+        row_frags_gload<T>(vf[kt], Vb, p.ld_v * ES, key, S, g);
+        const bool ok = key < S;
+        const float mv = (MODE != 0 && ok) ? p.mask[(long)b * S + key] : 0.f;
+        kadd[kt] = ok ? (MODE == 1 ? mv : 0.f) : -INFINITY;
+        cmk[kt] = (MODE == 2) ? mv : 0.f;
+    }
+    f32x4 dVt[4][2], dKt[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { dVt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float dosum_part = 0.f;
+
+    const int nqt = (S + BQ - 1) / BQ;
+    uint4 rq[NCH], rdo[NCH];
+    float r_lse = 0.f, r_delta = 0.f;
+    auto gload = [&](int t) {
+        tile_gload<T, BQ, true>(rq, Qb, p.ld_q * ES, t * BQ, S, tid);
+        tile_gload<T, BQ, true>(rdo, dOb, p.ld_do * ES, t * BQ, S, tid);
+        if (tid < BQ) {
+            const int q = t * BQ + tid;
+            r_lse = q < S ? lseb[q] : 0.f;
+            r_delta = q < S ? deltab[q] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF_B;
+        tile_lstore_row<T, BQ>(rq, base, tid);
+        tile_lstore_row<T, BQ>(rdo, base + ROW_B, tid);
+        tile_lstore_nat<T, BQ>(rq, base + 2 * ROW_B, tid);
+        tile_lstore_nat<T, BQ>(rdo, base + 2 * ROW_B + NAT_B, tid);
+        if (tid < BQ) {
+            float* f = reinterpret_cast<float*>(base + 2 * ROW_B + 2 * NAT_B);
+            f[tid] = r_lse; f[BQ + tid] = r_delta;
+        }
+    };
+    gload(0); lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nqt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nqt) gload(t + 1);
+        const char* Qrow = smem + cur * BUF_B;
+        const char* dOrow = Qrow + ROW_B;
+        const char* Qnat = Qrow + 2 * ROW_B;
+        const char* dOnat = Qnat + NAT_B;
+        const float* lse_s = reinterpret_cast<const float*>(dOnat + NAT_B);
+        const float* delta_s = lse_s + BQ;
+        const int qbase = t * BQ;
+
+        f32x4 sacc[2][2], dpacc[2][2];   // [qt][kt]: rows(regs) = query, cols(lanes) = key
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { sacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < NSD; ++s)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const uint4 aq = *reinterpret_cast<const uint4*>(Qrow + H::row_off(16 * qt + i, 4 * s + g));
+                const uint4 ad = *reinterpret_cast<const uint4*>(dOrow + H::row_off(16 * qt + i, 4 * s + g));
+                mma16<T>(aq, kf[0][s], sacc[qt][0]);
+                mma16<T>(aq, kf[1][s], sacc[qt][1]);
+                mma16<T>(ad, vf[0][s], dpacc[qt][0]);
+                mma16<T>(ad, vf[1][s], dpacc[qt][1]);
+            }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
+            const f32x4 D = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool qok = (qbase + 16 * qt + 4 * g + r) < S;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const float pr = qok ? __expf(sacc[qt][kt][r] * p.scale + kadd[kt] - L[r]) : 0.f;
+                    sacc[qt][kt][r] = pr;
+                    dpacc[qt][kt][r] = pr * (dpacc[qt][kt][r] - D[r]) * p.scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < BQ / KSTEP; ++ks) {
+            uint4 pb[2], dsb[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 tl[2];
+                tl[0] = sacc[ks * ET<T>::ACC_TILES][kt]; tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][kt];
+                pb[kt] = acc_to_kfrag<T>(tl);
+                tl[0] = dpacc[ks * ET<T>::ACC_TILES][kt]; tl[1] = dpacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][kt];
+                dsb[kt] = acc_to_kfrag<T>(tl);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 a1 = frag_kstrided<T>(dOnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                mma16<T>(a1, pb[0], dVt[dt][0]);
+                mma16<T>(a1, pb[1], dVt[dt][1]);
+                const uint4 a2 = frag_kstrided<T>(Qnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                mma16<T>(a2, dsb[0], dKt[dt][0]);
+                mma16<T>(a2, dsb[1], dKt[dt][1]);
+            }
+        }
+        if (MODE == 2) {   // sum_q dO[q][d]  (rows past S were zero-filled)
+            const int d = tid & 63, rq8 = tid >> 6;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                dosum_part += ET<T>::ld(reinterpret_cast<const T*>(dOnat + (rq8 * 8 + rr) * H::PITCH_N) + d);
+        }
+        if (t + 1 < nqt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (MODE == 2) {
+        red[wave * 64 + lane] = dosum_part;
+        __syncthreads();
+        if (tid < 64) red[256 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + 16 * kt + i;
+        if (key < S) {
+            T* dkrow = reinterpret_cast<T*>(p.dk) + ((long)b * S + key) * p.ld_dk + head * 64;
+            T* dvrow = reinterpret_cast<T*>(p.dv) + ((long)b * S + key) * p.ld_dv + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 dvv = dVt[dt][kt];
+                if (MODE == 2) dvv += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g) * cmk[kt];
+                st4(dvrow + 16 * dt + 4 * g, dvv);
+                st4(dkrow + 16 * dt + 4 * g, dKt[dt][kt]);
+            }
+        }
+    }
+}
+
+// ================================================================================================= backward: dQ
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+    using H = HD<T>;
+    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
+    constexpr int NCH = BKV * H::ROWCH / 256;
+    constexpr int ROW_B = BKV * H::ROWB, NAT_B = BKV * H::PITCH_N;
+    constexpr int BUF_B = 2 * ROW_B + NAT_B + BKV * 4;   // Krow, Vrow, Knat, kadd
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long hoff = (long)head * 64 * ES;
+    const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
+    const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
+    const char* Vb = p.v + (long)b * S * p.ld_v * ES + hoff;
+    const char* dOb = p.dout + (long)b * S * p.ld_do * ES + hoff;
+    const float* maskb = p.mask ? p.mask + (long)b * S : nullptr;
+
+    uint4 qf[2][NSD], dof[2][NSD];
+    float lse_q[2], delta_q[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + 16 * qt + i;
+        row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q, S, g);
+        row_frags_gload<T>(dof[qt], dOb, p.ld_do * ES, q, S, g);
+        if (q >= S) q = S - 1;
+        lse_q[qt] = p.lse[((long)b * p.nh + head) * S + q];
+        delta_q[qt] = p.delta[((long)b * p.nh + head) * S + q];
+    }
+    f32x4 dQt[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { dQt[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dQt[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nkt = (S + BKV - 1) / BKV;
+    uint4 rk[NCH], rv[NCH];
+    float r_kadd = 0.f;
+    auto gload = [&](int t) {
+        tile_gload<T, BKV, false>(rk, Kb, p.ld_k * ES, t * BKV, S, tid);
+        tile_gload<T, BKV, false>(rv, Vb, p.ld_v * ES, t * BKV, S, tid);
+        if (tid < BKV) {
+            const int key = t * BKV + tid;
+            const bool ok = key < S;
+            r_kadd = ok ? (MODE == 1 ? maskb[key] : 0.f) : -INFINITY;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF_B;
+        tile_lstore_row<T, BKV>(rk, base, tid);
+        tile_lstore_row<T, BKV>(rv, base + ROW_B, tid);
+        tile_lstore_nat<T, BKV>(rk, base + 2 * ROW_B, tid);
+        if (tid < BKV) reinterpret_cast<float*>(base + 2 * ROW_B + NAT_B)[tid] = r_kadd;
+    };
+    gload(0); lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nkt) gload(t + 1);
+        const char* Krow = smem + cur * BUF_B;
+        const char* Vrow = Krow + ROW_B;
+        const char* Knat = Krow + 2 * ROW_B;
+        const float* kadd = reinterpret_cast<const float*>(Knat + NAT_B);
+
+        f32x4 sacc[4][2], dpacc[4][2];   // [kt][qt]: rows(regs) = key, cols(lanes) = query
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { sacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < NSD; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const uint4 ak = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
+                const uint4 av = *reinterpret_cast<const uint4*>(Vrow + H::row_off(16 * kt + i, 4 * s + g));
+                mma16<T>(ak, qf[0][s], sacc[kt][0]);
+                mma16<T>(ak, qf[1][s], sacc[kt][1]);
+                mma16<T>(av, dof[0][s], dpacc[kt][0]);
+                mma16<T>(av, dof[1][s], dpacc[kt][1]);
+            }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __expf(sacc[kt][qt][r] * p.scale + ka[r] - lse_q[qt]);
+                    sacc[kt][qt][r] = pr * (dpacc[kt][qt][r] - delta_q[qt]) * p.scale;   // dS^T
+                }
+        }
+#pragma unroll
+        for (int ks = 0; ks < BKV / KSTEP; ++ks) {
+            uint4 dsb[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 tl[2];
+                tl[0] = sacc[ks * ET<T>::ACC_TILES][qt]; tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
+                dsb[qt] = acc_to_kfrag<T>(tl);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint4 a = frag_kstrided<T>(Knat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                mma16<T>(a, dsb[0], dQt[dt][0]);
+                mma16<T>(a, dsb[1], dQt[dt][1]);
+            }
+        }
+        if (t + 1 < nkt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 16 * qt + i;
+        if (q < S) {
+            T* dqrow = reinterpret_cast<T*>(p.dq) + ((long)b * S + q) * p.ld_dq + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) st4(dqrow + 16 * dt + 4 * g, dQt[dt][qt]);
+        }
+    }
+}
+
+template <typename T> constexpr size_t fwd_lds() {
+    return 2 * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
+}
+template <typename T> constexpr size_t dkdv_lds() {
+    return 2 * (2 * 32 * HD<T>::ROWB + 2 * 32 * HD<T>::PITCH_N + 2 * 32 * 4) + (256 + 64) * 4;
+}
+template <typename T> constexpr size_t dq_lds() { return 2 * (2 * 64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 64 * 4); }
+
+static int check(const tav_attn_args* a, bool bwd) {
+    if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse) return TAV_ERR_NULL;
+    if (a->B <= 0 || a->S <= 0 || a->nheads <= 0) return TAV_ERR_SHAPE;
+    if (a->dtype != TAV_BF16 && a->dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if (a->mask_mode < 0 || a->mask_mode > 2) return TAV_ERR_SHAPE;
+    if (a->mask_mode != 0 && !a->key_mask) return TAV_ERR_NULL;
+    if (a->mask_mode == 2 && !a->corr) return TAV_ERR_NULL;
+    const int pk = a->dtype == TAV_BF16 ? 8 : 4;
+    if (a->ld_q % pk || a->ld_k % pk || a->ld_v % pk || a->ld_o % 4) return TAV_ERR_ALIGN;
+    if (a->ld_q < a->nheads * 64 || a->ld_k < a->nheads * 64 || a->ld_v < a->nheads * 64 || a->ld_o < a->nheads * 64) return TAV_ERR_SHAPE;
+    if (bwd) {
+        if (!a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return TAV_ERR_NULL;
+        if (a->ld_do % pk || a->ld_dq % 4 || a->ld_dk % 4 || a->ld_dv % 4) return TAV_ERR_ALIGN;
+    }
+    return 0;
+}
+static AttnP pack(const tav_attn_args* a) {
+    AttnP p;
+    p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->o;
+    p.mask = a->key_mask; p.lse = a->lse; p.corr = a->corr;
+    p.dout = (const char*)a->dout; p.dq = (char*)a->dq; p.dk = (char*)a->dk; p.dv = (char*)a->dv; p.delta = a->delta;
+    p.B = (int)a->B; p.S = (int)a->S; p.nh = (int)a->nheads;
+    p.ld_q = a->ld_q; p.ld_k = a->ld_k; p.ld_v = a->ld_v; p.ld_o = a->ld_o; p.ld_do = a->ld_do;
+    p.ld_dq = a->ld_dq; p.ld_dk = a->ld_dk; p.ld_dv = a->ld_dv;
+    p.scale = a->scale;
+    return p;
+}
+
+template <typename T, int MODE> static int launch_fwd(const AttnP& p, hipStream_t st) {
+    dim3 grid((p.S + 127) / 128, p.nh, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, MODE>), grid, dim3(256), fwd_lds<T>(), st, p);
+    return (int)hipGetLastError();
+}
+template <typename T, int MODE> static int launch_bwd(const AttnP& p, hipStream_t st) {
+    const long rows = (long)p.B * p.S * p.nh;
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    dim3 grid((p.S + 127) / 128, p.nh, p.B);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE>), grid, dim3(256), dkdv_lds<T>(), st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE>), grid, dim3(256), dq_lds<T>(), st, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace tav
+
+using namespace tav;
+
+extern "C" int tav_attn_fwd(const tav_attn_args* a, void* stream) {
+    int e = check(a, false);
+    if (e) return e;
+    const AttnP p = pack(a);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == TAV_BF16) {
+        switch (a->mask_mode) { case 0: return launch_fwd<bf16, 0>(p, st); case 1: return launch_fwd<bf16, 1>(p, st); default: return launch_fwd<bf16, 2>(p, st); }
+    }
+    switch (a->mask_mode) { case 0: return launch_fwd<float, 0>(p, st); case 1: return launch_fwd<float, 1>(p, st); default: return launch_fwd<float, 2>(p, st); }
+}
+
+extern "C" int tav_attn_bwd(const tav_attn_args* a, void* stream) {
+    int e = check(a, true);
+    if (e) return e;
+    const AttnP p = pack(a);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == TAV_BF16) {
+        switch (a->mask_mode) { case 0: return launch_bwd<bf16, 0>(p, st); case 1: return launch_bwd<bf16, 1>(p, st); default: return launch_bwd<bf16, 2>(p, st); }
+    }
+    switch (a->mask_mode) { case 0: return launch_bwd<float, 0>(p, st); case 1: return launch_bwd<float, 1>(p, st); default: return launch_bwd<float, 2>(p, st); }
+}

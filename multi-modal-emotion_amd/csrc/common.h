@@ -1,0 +1,141 @@
+// Device-side building blocks shared by every kernel of libtavhip (gfx950 / CDNA4 only).
+//
+// Conventions used throughout csrc/:
+//   * wave = 64 lanes; lane = threadIdx.x & 63; for MFMA work lane = (g, i) with i = lane & 15
+//     (the "row/col within a 16x16 tile" index) and g = lane >> 4 (the k-group, 0..3).
+//   * one "chunk" = 16 bytes = PK elements (8 bf16 or 4 f32).  Every matrix product in the library
+//     is built from mma16<T>(): a 16x16 output tile accumulated over KSTEP = 4*PK values of k
+//     (one v_mfma_f32_16x16x32_bf16, or four v_mfma_f32_16x16x4_f32 for exact-f32 parity runs).
+//   * operand k-sets.  For one mma16 step starting at k0, lane group g supplies
+//         row-chunk operand  (k contiguous in memory):  k = k0 + PK*g + j            j < PK
+//         k-strided operand  (k is the slow index)   :  bf16: k = k0 + 4g + j (j<4), k0 + 16 + 4g + (j-4) (j>=4)
+//                                                       f32 : k = k0 + 4g + j (j<4)
+//     The second map is exactly the order in which a lane already holds a 16x16 accumulator tile
+//     (rows 4g..4g+3), so an accumulator can be fed back as an operand with no lane movement;
+//     two operands of one product must use the same map.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tav {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+struct bf16 { uint16_t x; };   // storage tag for bfloat16 tensors
+
+#define TAV_DEV __device__ __forceinline__
+
+TAV_DEV float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+TAV_DEV uint32_t f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+TAV_DEV uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int PK = 4, KSTEP = 16, ES = 4, ACC_TILES = 1;
+    static TAV_DEV float ld(const float* p) { return *p; }
+    static TAV_DEV void st(float* p, float v) { *p = v; }
+};
+template <> struct ET<bf16> {
+    static constexpr int PK = 8, KSTEP = 32, ES = 2, ACC_TILES = 2;
+    static TAV_DEV float ld(const bf16* p) { return bf16_bits_to_f32(p->x); }
+    static TAV_DEV void st(bf16* p, float v) { p->x = (uint16_t)f32_to_bf16_bits(v); }
+};
+
+// ---- 4-wide vector load / store of T as floats (addresses 4-element aligned) -------------------
+TAV_DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+TAV_DEV f32x4 ld4(const bf16* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    f32x4 r = {bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+               bf16_bits_to_f32(u.y >> 16)};
+    return r;
+}
+TAV_DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+TAV_DEV void st4(bf16* p, f32x4 v) {
+    uint2 u;
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+// ---- one 16x16 tile step ------------------------------------------------------------------------
+// c[r] (r=0..3) is C[row 4g+r][col i]; "a" supplies C's row index, "b" its column index.
+template <typename T> TAV_DEV void mma16(const uint4& a, const uint4& b, f32x4& c);
+template <> TAV_DEV void mma16<bf16>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
+                                                0, 0);
+}
+template <> TAV_DEV void mma16<float>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+}
+
+// ---- LDS helpers --------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+TAV_DEV uint2 lds_read_tr16(const char* p) {
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+// k-strided operand fragment from a "natural" LDS tile: tile[krow][col] with `pitch` bytes per row.
+// Returns, for lane (g, i), the PK/… values {tile[k][col0 + i]} over this lane group's k-set (see header).
+// EXEC must be all ones (the bf16 form is a cross-lane gather); callers pad instead of masking.
+template <typename T> TAV_DEV uint4 frag_kstrided(const char* tile, int pitch, int krow0, int col0, int lane);
+template <> TAV_DEV uint4 frag_kstrided<bf16>(const char* tile, int pitch, int krow0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const char* a0 = tile + (krow0 + 4 * g + q) * pitch + (col0 + 4 * p) * 2;
+    uint2 lo = lds_read_tr16(a0);
+    uint2 hi = lds_read_tr16(a0 + 16 * pitch);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+template <> TAV_DEV uint4 frag_kstrided<float>(const char* tile, int pitch, int krow0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const char* a0 = tile + (krow0 + 4 * g) * pitch + (col0 + i) * 4;
+    uint4 r;
+    r.x = *reinterpret_cast<const uint32_t*>(a0);
+    r.y = *reinterpret_cast<const uint32_t*>(a0 + pitch);
+    r.z = *reinterpret_cast<const uint32_t*>(a0 + 2 * pitch);
+    r.w = *reinterpret_cast<const uint32_t*>(a0 + 3 * pitch);
+    return r;
+}
+
+// Accumulator tile(s) -> k-strided operand.  bf16 takes two consecutive 16-row tiles (32 k values),
+// f32 one tile (16 k values); element order matches frag_kstrided's k-set.
+template <typename T> TAV_DEV uint4 acc_to_kfrag(const f32x4* tiles);
+template <> TAV_DEV uint4 acc_to_kfrag<bf16>(const f32x4* t) {
+    return make_uint4(pack_bf16x2(t[0][0], t[0][1]), pack_bf16x2(t[0][2], t[0][3]), pack_bf16x2(t[1][0], t[1][1]),
+                      pack_bf16x2(t[1][2], t[1][3]));
+}
+template <> TAV_DEV uint4 acc_to_kfrag<float>(const f32x4* t) {
+    return make_uint4(__float_as_uint(t[0][0]), __float_as_uint(t[0][1]), __float_as_uint(t[0][2]),
+                      __float_as_uint(t[0][3]));
+}
+
+// ---- wave reductions ----------------------------------------------------------------------------
+TAV_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+TAV_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU (nn.GELU() default; reference utils/TAVFormer.py:398) and its derivative
+TAV_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+TAV_DEV float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+}  // namespace tav

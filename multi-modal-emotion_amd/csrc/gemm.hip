@@ -1,0 +1,425 @@
+// MFMA GEMMs of the TAV hot path.
+//
+//   gemm_nt : C[z][m][n] = epi( sum_k A[z][m][k] * B[z][n][k] )        forward linears, dgrad (with W^T copies),
+//                                                                       conv1d-as-GEMM (overlapping A rows), grouped pos-conv
+//   gemm_tn : S[s][n1][n2] = sum_{m in split s} A[m][n1] * B[m][n2]     wgrad (dW = dY^T X), split over the token axis,
+//             followed by splitk_reduce (deterministic, no atomics)
+//
+// Replaces the ATen/cuBLAS call sites listed in SURVEY.md §2.1 (reference utils/TAVFormer.py:348-350,393-439;
+// HF roberta/wav2vec2/videomae linears; wav2vec2 conv stack).
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles of 16x16),
+// K-tile = 128 bytes per row (64 bf16 / 32 f32), register-staged global->LDS double buffer, one barrier per K-tile.
+// LDS image of the NT kernel: [row][8 chunks of 16 B], chunk index XOR-swizzled with (row>>1)&7 so that the
+// ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group) are bank-conflict free.
+#include "common.h"
+#include "tavhip_internal.h"
+
+namespace tav {
+
+// ------------------------------------------------------------------------------------------------
+struct GemmNT {
+    const char* A; const char* B; char* C; char* Cpre; const float* bias; const char* gelu_in; const float* resid;
+    int M, N, K;
+    long lda, ldb, ldc, ld_pre, ld_gelu, ld_resid;   // row strides in elements
+    int nzg;
+    long a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg;  // batch strides in elements (C strides apply to Cpre/gelu_in/resid too)
+    int act, accumulate;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+TAV_DEV int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.
+// Give each XCD a contiguous band of tiles (bijective for any grid size), and walk n fastest inside the band so
+// neighbouring tiles of one XCD reuse the same A rows.
+TAV_DEV int xcd_remap(int id, int total) {
+    const int q = total >> 3, r = total & 7, x = id & 7, k = id >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
+    constexpr int ES = ET<T>::ES;
+    constexpr int BM = 128, BN = 128;
+    constexpr int TILE_BYTES = BM * 128;  // one operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                    // [2][BM][128B]  activations (m)
+    char* sB = smem + 2 * TILE_BYTES;   // [2][BN][128B]  weights (n)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tm_idx = tile / p.tiles_n, tn_idx = tile - tm_idx * p.tiles_n;
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+    const int z = blockIdx.y, zb = z / p.nzg, zg = z - zb * p.nzg;
+
+    const char* Ab = p.A + (zb * p.a_zb + zg * p.a_zg) * ES;
+    const char* Bb = p.B + (zb * p.b_zb + zg * p.b_zg) * ES;
+
+    // staging: thread -> (row r0 + 32*pass, chunk c)
+    const int c = tid & 7, r0 = tid >> 3;
+    const char* ga[4];
+    const char* gb[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        int ra = m0 + r0 + 32 * ps; ra = ra < p.M ? ra : p.M - 1;
+        int rb = n0 + r0 + 32 * ps; rb = rb < p.N ? rb : p.N - 1;
+        ga[ps] = Ab + (long)ra * p.lda * ES + c * 16;
+        gb[ps] = Bb + (long)rb * p.ldb * ES + c * 16;
+    }
+    int lds_w[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) { const int r = r0 + 32 * ps; lds_w[ps] = r * 128 + swz(r, c) * 16; }
+
+    f32x4 acc[4][4];  // [tn][tm]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K * ES / 128;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define TAV_GLOAD(KT)                                                            \
+    do {                                                                         \
+        const long ko = (long)(KT) * 128;                                        \
+        ra0 = *reinterpret_cast<const uint4*>(ga[0] + ko); ra1 = *reinterpret_cast<const uint4*>(ga[1] + ko); \
+        ra2 = *reinterpret_cast<const uint4*>(ga[2] + ko); ra3 = *reinterpret_cast<const uint4*>(ga[3] + ko); \
+        rb0 = *reinterpret_cast<const uint4*>(gb[0] + ko); rb1 = *reinterpret_cast<const uint4*>(gb[1] + ko); \
+        rb2 = *reinterpret_cast<const uint4*>(gb[2] + ko); rb3 = *reinterpret_cast<const uint4*>(gb[3] + ko); \
+    } while (0)
+#define TAV_LSTORE(BUF)                                                          \
+    do {                                                                         \
+        char* nA = sA + (BUF) * TILE_BYTES; char* nB = sB + (BUF) * TILE_BYTES;  \
+        *reinterpret_cast<uint4*>(nA + lds_w[0]) = ra0; *reinterpret_cast<uint4*>(nA + lds_w[1]) = ra1; \
+        *reinterpret_cast<uint4*>(nA + lds_w[2]) = ra2; *reinterpret_cast<uint4*>(nA + lds_w[3]) = ra3; \
+        *reinterpret_cast<uint4*>(nB + lds_w[0]) = rb0; *reinterpret_cast<uint4*>(nB + lds_w[1]) = rb1; \
+        *reinterpret_cast<uint4*>(nB + lds_w[2]) = rb2; *reinterpret_cast<uint4*>(nB + lds_w[3]) = rb3; \
+    } while (0)
+    TAV_GLOAD(0);
+    TAV_LSTORE(0);
+    __syncthreads();
+
+    // fragment read offsets (row part); chunk part depends on the k-step
+    int row_a[4], row_b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { row_a[t] = wm * 64 + t * 16 + i; row_b[t] = wn * 64 + t * 16 + i; }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // prefetch the next K-tile into registers (the last iteration re-reads its own tile: harmless, keeps the
+        // loads unconditional so the staging registers never go through scratch)
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;
+        TAV_GLOAD(ktn);
+        const char* cA = sA + cur * TILE_BYTES;
+        const char* cB = sB + cur * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = *reinterpret_cast<const uint4*>(cA + row_a[t] * 128 + swz(row_a[t], 4 * s + g) * 16);
+                fb[t] = *reinterpret_cast<const uint4*>(cB + row_b[t] * 128 + swz(row_b[t], 4 * s + g) * 16);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) mma16<T>(fb[tn], fa[tm], acc[tn][tm]);
+        }
+        TAV_LSTORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef TAV_GLOAD
+#undef TAV_LSTORE
+
+    // epilogue: lane holds C[m = .. + i][n = .. + 4g + r], r = 0..3
+    const long coff = zb * p.c_zb + zg * p.c_zg;
+    TO* C = reinterpret_cast<TO*>(p.C) + coff;
+    TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
+    const T* Gin = p.gelu_in ? reinterpret_cast<const T*>(p.gelu_in) + coff : nullptr;
+    const float* R = p.resid ? p.resid + coff : nullptr;
+    const float* bias = p.bias ? p.bias + zg * p.bias_zg : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * g;
+            if (n >= p.N) continue;
+            f32x4 v = acc[tn][tm] * p.alpha;
+            if (bias) v += ld4(bias + n);
+            if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
+            if (p.act == 1) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
+            if (Gin) {
+                f32x4 u = ld4(Gin + (long)m * p.ld_gelu + n);
+                v[0] *= gelu_grad_f(u[0]); v[1] *= gelu_grad_f(u[1]); v[2] *= gelu_grad_f(u[2]); v[3] *= gelu_grad_f(u[3]);
+            }
+            if (R) v += ld4(R + (long)m * p.ld_resid + n);
+            if (p.accumulate) v += ld4(C + (long)m * p.ldc + n);
+            st4(C + (long)m * p.ldc + n, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GemmTN {
+    const char* A; const char* B; float* S;   // S: slabs [nsplit][N1][N2] fp32
+    int N1, N2;
+    long lda, ldb;          // row strides (elements) of the token-major operands
+    int rows_per_batch;     // T: tokens per batch entry (reduction axis = nbatch * T)
+    long a_zb, b_zb;        // batch strides (elements)
+    int chunk_rows;         // tokens per split (multiple of 64)
+    int chunks_per_batch;
+    int tiles_1, tiles_2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+    constexpr int ES = ET<T>::ES, PK = ET<T>::PK, KSTEP = ET<T>::KSTEP;
+    constexpr int BT = 128;                       // tile edge (elements) on both output axes
+    constexpr int ROWB = BT * ES;                 // bytes per natural row
+    constexpr int PITCH = ROWB + (ES == 2 ? 32 : 16);   // bf16: +8 banks/row (tr_b16 reads of 8 rows hit 64 distinct banks); f32: 4 rows = +16 banks (b32 reads)
+    constexpr int KT = 64;                        // tokens per K-tile
+    constexpr int TILE_BYTES = KT * PITCH;
+    constexpr int CPR = ROWB / 16;                // chunks per row (16 or 32)
+    constexpr int RSTEP = 256 / CPR;              // rows covered per pass (16 or 8)
+    constexpr int NPASS = KT / RSTEP;             // 4 or 8
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                    // [2][KT][PITCH]  dY  (n1 along the row)
+    char* sB = smem + 2 * TILE_BYTES;   // [2][KT][PITCH]  X   (n2 along the row)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int w1 = wave >> 1, w2 = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, p.tiles_1 * p.tiles_2);
+    const int t1 = tile / p.tiles_2, t2 = tile - t1 * p.tiles_2;
+    const int n1_0 = t1 * BT, n2_0 = t2 * BT;
+    const int split = blockIdx.y;
+    const int zb = split / p.chunks_per_batch, ck = split - zb * p.chunks_per_batch;
+    const int row_begin = ck * p.chunk_rows;
+    int row_end = row_begin + p.chunk_rows; row_end = row_end < p.rows_per_batch ? row_end : p.rows_per_batch;
+
+    const char* Ab = p.A + zb * p.a_zb * ES;
+    const char* Bb = p.B + zb * p.b_zb * ES;
+
+    const int c = tid % CPR, r0 = tid / CPR;
+    const bool a_col_ok = (n1_0 + c * PK) < p.N1;
+    const bool b_col_ok = (n2_0 + c * PK) < p.N2;
+    const char* ga = Ab + (long)(n1_0 + c * PK) * ES;
+    const char* gb = Bb + (long)(n2_0 + c * PK) * ES;
+
+    f32x4 acc[4][4];  // [t1][t2]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (row_end - row_begin + KT - 1) / KT;
+    uint4 ra_[NPASS], rb_[NPASS];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = row_begin + kt * KT + r0 + ps * RSTEP;
+            const bool ok = row < row_end;
+            ra_[ps] = (ok && a_col_ok) ? *reinterpret_cast<const uint4*>(ga + (long)row * p.lda * ES) : make_uint4(0, 0, 0, 0);
+            rb_[ps] = (ok && b_col_ok) ? *reinterpret_cast<const uint4*>(gb + (long)row * p.ldb * ES) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int off = (r0 + ps * RSTEP) * PITCH + c * 16;
+            *reinterpret_cast<uint4*>(sA + buf * TILE_BYTES + off) = ra_[ps];
+            *reinterpret_cast<uint4*>(sB + buf * TILE_BYTES + off) = rb_[ps];
+        }
+    };
+    if (nk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* cA = sA + cur * TILE_BYTES;
+        const char* cB = sB + cur * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < KT / KSTEP; ++s) {
+            uint4 f1[4], f2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f1[t] = frag_kstrided<T>(cA, PITCH, s * KSTEP, w1 * 64 + t * 16, lane);
+                f2[t] = frag_kstrided<T>(cB, PITCH, s * KSTEP, w2 * 64 + t * 16, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* S = p.S + (long)split * p.N1 * p.N2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n1 = n1_0 + w1 * 64 + a * 16 + i;
+        if (n1 >= p.N1) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n2 = n2_0 + w2 * 64 + b * 16 + 4 * g;
+            if (n2 >= p.N2) continue;
+            st4(S + (long)n1 * p.N2 + n2, acc[a][b]);
+        }
+    }
+}
+
+// out[n1][perm(n2)] (+)= sum_s S[s][n1][n2];  perm(n2) = (n2 % inner) * outer + n2 / inner  (outer = 1: identity).
+// Used with inner = C_in, outer = kernel width to hand conv wgrads back in nn.Conv1d's [co][ci][k] order.
+__global__ void splitk_reduce_kernel(const float* __restrict__ S, float* __restrict__ out, int nsplit, long n_elems, int N2,
+                                     int inner, int outer, int accumulate, float scale) {
+    const long idx4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (idx4 >= n_elems) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) v += ld4(S + (long)s * n_elems + idx4);
+    v *= scale;
+    if (outer == 1) {
+        if (accumulate) v += ld4(out + idx4);
+        st4(out + idx4, v);
+    } else {
+        const long n1 = idx4 / N2; const int n2 = (int)(idx4 - n1 * N2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = n2 + e;
+            const long o = n1 * N2 + (long)(q % inner) * outer + q / inner;
+            out[o] = accumulate ? out[o] + v[e] : v[e];
+        }
+    }
+}
+
+// column sums (bias gradients): out[n] (+)= sum_m X[m][n], two deterministic stages.
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ X, float* __restrict__ part, int M, int N, long ld, int rows_per_block) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r_begin = blockIdx.y * rows_per_block;
+    int r_end = r_begin + rows_per_block; r_end = r_end < M ? r_end : M;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = r_begin; r < r_end; ++r) s += ET<T>::ld(X + (long)r * ld + n);
+    part[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(long)k * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+}  // namespace tav
+
+using namespace tav;
+
+extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a || !a->A || !a->B || !a->C) return TAV_ERR_NULL;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return TAV_ERR_SHAPE;
+    const int es = a->in_dtype == TAV_BF16 ? 2 : 4;
+    if (a->in_dtype != TAV_BF16 && a->in_dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if (a->in_dtype == TAV_F32 && a->out_dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if ((a->K * es) % 128 != 0) return TAV_ERR_SHAPE;      // K-tile = 128 bytes
+    if (a->N % 4 != 0) return TAV_ERR_SHAPE;
+    const int pk = 16 / es;
+    if (a->lda % pk || a->ldb % pk || a->ldc % 4) return TAV_ERR_ALIGN;
+    if (a->a_zb % pk || a->a_zg % pk || a->b_zb % pk || a->b_zg % pk || a->c_zb % 4 || a->c_zg % 4) return TAV_ERR_ALIGN;
+    GemmNT p;
+    p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C; p.Cpre = (char*)a->C_pre; p.bias = a->bias;
+    p.gelu_in = (const char*)a->gelu_in; p.resid = a->resid;
+    p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ld_pre = a->ld_pre; p.ld_gelu = a->ld_gelu_in; p.ld_resid = a->ld_resid;
+    p.nzg = a->nzg > 0 ? a->nzg : 1;
+    const int nzb = a->nzb > 0 ? a->nzb : 1;
+    p.a_zb = a->a_zb; p.a_zg = a->a_zg; p.b_zb = a->b_zb; p.b_zg = a->b_zg; p.c_zb = a->c_zb; p.c_zg = a->c_zg; p.bias_zg = a->bias_zg;
+    p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
+    p.tiles_m = (p.M + 127) / 128; p.tiles_n = (p.N + 127) / 128;
+    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(256);
+    const size_t lds = 4 * 128 * 128;
+    if (a->in_dtype == TAV_BF16) {
+        if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16, bf16>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16, float>), grid, block, lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, lds, stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit) {
+    if (!chunk_rows || !nsplit || n1 <= 0 || n2 <= 0 || rows_per_batch <= 0 || nbatch <= 0) return TAV_ERR_SHAPE;
+    const long tiles = ((n1 + 127) / 128) * ((n2 + 127) / 128);
+    // aim at ~2 workgroups per CU (512), at least 256 tokens per split
+    long want = (512 + tiles - 1) / tiles;
+    long per_batch = (want + nbatch - 1) / nbatch;
+    if (per_batch < 1) per_batch = 1;
+    long cr = (rows_per_batch + per_batch - 1) / per_batch;
+    if (cr < 256) cr = 256;
+    cr = ((cr + 63) / 64) * 64;
+    const long cpb = (rows_per_batch + cr - 1) / cr;
+    *chunk_rows = (int32_t)cr;
+    *nsplit = (int32_t)(cpb * nbatch);
+    return 0;
+}
+
+extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a || !a->A || !a->B || !a->slabs || !a->out) return TAV_ERR_NULL;
+    if (a->N1 <= 0 || a->N2 <= 0 || a->rows_per_batch <= 0 || a->nbatch <= 0) return TAV_ERR_SHAPE;
+    if (a->dtype != TAV_BF16 && a->dtype != TAV_F32) return TAV_ERR_DTYPE;
+    const int es = a->dtype == TAV_BF16 ? 2 : 4, pk = 16 / es;
+    if (a->N1 % pk || a->N2 % pk || a->N2 % 4) return TAV_ERR_SHAPE;
+    if (a->lda % pk || a->ldb % pk || a->a_zb % pk || a->b_zb % pk) return TAV_ERR_ALIGN;
+    if (a->chunk_rows <= 0 || a->chunk_rows % 64) return TAV_ERR_SHAPE;
+    GemmTN p;
+    p.A = (const char*)a->A; p.B = (const char*)a->B; p.S = a->slabs;
+    p.N1 = (int)a->N1; p.N2 = (int)a->N2; p.lda = a->lda; p.ldb = a->ldb;
+    p.rows_per_batch = (int)a->rows_per_batch; p.a_zb = a->a_zb; p.b_zb = a->b_zb;
+    p.chunk_rows = a->chunk_rows;
+    p.chunks_per_batch = (int)((a->rows_per_batch + a->chunk_rows - 1) / a->chunk_rows);
+    const int nsplit = p.chunks_per_batch * (int)a->nbatch;
+    if (nsplit != a->nsplit) return TAV_ERR_SHAPE;
+    p.tiles_1 = (p.N1 + 127) / 128; p.tiles_2 = (p.N2 + 127) / 128;
+    dim3 grid(p.tiles_1 * p.tiles_2, nsplit), block(256);
+    if (a->dtype == TAV_BF16) {
+        const size_t lds = 4 * 64 * (256 + 32);
+        hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, block, lds, stream, p);
+    } else {
+        const size_t lds = 4 * 64 * (512 + 16);
+        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, lds, stream, p);
+    }
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    const long n_elems = (long)p.N1 * p.N2;
+    const int inner = a->perm_inner > 0 ? a->perm_inner : p.N2, outer = a->perm_outer > 0 ? a->perm_outer : 1;
+    if (outer > 1 && inner * outer != p.N2) return TAV_ERR_SHAPE;
+    const long nthreads = (n_elems + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a->slabs, a->out, nsplit,
+                       n_elems, p.N2, inner, outer, a->accumulate, a->scale == 0.f ? 1.f : a->scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_colsum(const void* x, int32_t dtype, int64_t M, int64_t N, int64_t ld, float* partials, int32_t nparts, float* out,
+                          int32_t accumulate, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !partials || !out) return TAV_ERR_NULL;
+    if (M <= 0 || N <= 0 || nparts <= 0) return TAV_ERR_SHAPE;
+    const int rows_per_block = (int)((M + nparts - 1) / nparts);
+    dim3 grid((unsigned)((N + 255) / 256), nparts), block(256);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, block, 0, stream, (const bf16*)x, partials, (int)M, (int)N, (long)ld, rows_per_block);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, stream, (const float*)x, partials, (int)M, (int)N, (long)ld, rows_per_block);
+    else return TAV_ERR_DTYPE;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partials, out, nparts, (int)N, accumulate);
+    return (int)hipGetLastError();
+}

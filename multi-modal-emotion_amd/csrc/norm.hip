@@ -1,0 +1,351 @@
+// LayerNorm (one wave64 per row, shuffle reductions, f32 statistics) and the wav2vec2 "group" norm
+// (GroupNorm with one group per channel == normalisation over time per (batch, channel)), both HBM-bound.
+// Replaces nn.LayerNorm / nn.GroupNorm call-sites of the path: reference utils/TAVFormer.py:237,239,108,118,
+// models/tav.py:439-447, HF roberta:336-340,394-398, HF wav2vec2:275-323,422-434,611-726, HF videomae:326-357.
+#include "common.h"
+#include "tavhip_internal.h"
+
+namespace tav {
+
+constexpr int LN_MAXV = 4;   // float4 vectors per lane: W <= 64*4*4 = 1024
+
+struct LnP {
+    const void* x; const float* gamma; const float* beta; float* y_f32; void* y_lp; float* mean; float* rstd;
+    const void* dy; const float* dx_add; float* dx_f32; void* dx_lp; float* partials;
+    long rows; int W; long ld_x, ld_y, ld_dy, ld_dx; float eps; int act;
+};
+
+template <typename TX, typename TL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = p.W >> 2;
+    const float invW = 1.f / (float)p.W;
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const TX* xr = reinterpret_cast<const TX*>(p.x) + row * p.ld_x;
+        f32x4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = (c < nv) ? ld4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+        const float mean = wave_sum(s) * invW;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nv) { const f32x4 d = v[j] - mean; q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invW + p.eps);
+        if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nv) {
+                f32x4 y = (v[j] - mean) * rstd * ld4(p.gamma + 4 * c) + ld4(p.beta + 4 * c);
+                if (p.act == 1) { y[0] = gelu_f(y[0]); y[1] = gelu_f(y[1]); y[2] = gelu_f(y[2]); y[3] = gelu_f(y[3]); }
+                if (p.y_f32) st4(p.y_f32 + row * p.ld_y + 4 * c, y);
+                if (p.y_lp) st4(reinterpret_cast<TL*>(p.y_lp) + row * p.ld_y + 4 * c, y);
+            }
+        }
+    }
+}
+
+template <typename TX, typename TDY, typename TL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = p.W >> 2;
+    const float invW = 1.f / (float)p.W;
+    f32x4 dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) { dg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const TX* xr = reinterpret_cast<const TX*>(p.x) + row * p.ld_x;
+        const TDY* dyr = reinterpret_cast<const TDY*>(p.dy) + row * p.ld_dy;
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        f32x4 xh[LN_MAXV], gdy[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nv) {
+                xh[j] = (ld4(xr + 4 * c) - mean) * rstd;
+                f32x4 d = ld4(dyr + 4 * c);
+                const f32x4 gam = ld4(p.gamma + 4 * c);
+                if (p.act == 1) {
+                    const f32x4 z = xh[j] * gam + ld4(p.beta + 4 * c);
+                    d[0] *= gelu_grad_f(z[0]); d[1] *= gelu_grad_f(z[1]); d[2] *= gelu_grad_f(z[2]); d[3] *= gelu_grad_f(z[3]);
+                }
+                dg[j] += d * xh[j];
+                db[j] += d;
+                gdy[j] = d * gam;
+                s1 += gdy[j][0] + gdy[j][1] + gdy[j][2] + gdy[j][3];
+                const f32x4 t = gdy[j] * xh[j];
+                s2 += t[0] + t[1] + t[2] + t[3];
+            } else { xh[j] = f32x4{0.f, 0.f, 0.f, 0.f}; gdy[j] = xh[j]; }
+        }
+        const float m1 = wave_sum(s1) * invW, m2 = wave_sum(s2) * invW;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nv) {
+                f32x4 dx = (gdy[j] - m1 - xh[j] * m2) * rstd;
+                if (p.dx_add) dx += ld4(p.dx_add + row * p.ld_dx + 4 * c);
+                if (p.dx_f32) st4(p.dx_f32 + row * p.ld_dx + 4 * c, dx);
+                if (p.dx_lp) st4(reinterpret_cast<TL*>(p.dx_lp) + row * p.ld_dx + 4 * c, dx);
+            }
+        }
+    }
+    if (!p.partials) return;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[wave][0][4 * c + e] = dg[j][e]; red[wave][1][4 * c + e] = db[j][e]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.W; c += 256) {
+        p.partials[((long)blockIdx.x * 2 + 0) * p.W + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        p.partials[((long)blockIdx.x * 2 + 1) * p.W + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+__global__ void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    float g = 0.f, b = 0.f;
+    for (int k = 0; k < nblocks; ++k) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+static inline int ln_blocks(long rows) {
+    long b = (rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+// ------------------------------------------------------------------------------------------------ group norm over time
+// x [B][T][C] channels-last.  stats pass: partial sums over a T-slice for 64 channels; apply pass element-wise.
+constexpr int GN_SPLIT = 16;
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ stats, float* part, int Tn, int C) {
+    __shared__ float red[4][64][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, b = blockIdx.z, sp = blockIdx.y;
+    const int per = (Tn + GN_SPLIT - 1) / GN_SPLIT, t0 = sp * per;
+    int t1 = t0 + per; t1 = t1 < Tn ? t1 : Tn;
+    float a0 = 0.f, a1 = 0.f;
+    float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
+    if (BWD) { mean = stats[((long)b * C + c) * 2]; rstd = stats[((long)b * C + c) * 2 + 1]; gam = gamma[c]; bet = beta[c]; }
+    for (int t = t0 + rg; t < t1; t += 4) {
+        const float v = ET<T>::ld(x + ((long)b * Tn + t) * C + c);
+        if (!BWD) { a0 += v; a1 += v * v; }
+        else {
+            const float xh = (v - mean) * rstd;
+            const float dz = ET<T>::ld(dy + ((long)b * Tn + t) * C + c) * gelu_grad_f(xh * gam + bet);
+            a0 += dz; a1 += dz * xh;
+        }
+    }
+    red[rg][threadIdx.x & 63][0] = a0; red[rg][threadIdx.x & 63][1] = a1;
+    __syncthreads();
+    if (rg == 0) {
+        const int l = threadIdx.x;
+        part[(((long)b * GN_SPLIT + sp) * C + c) * 2 + 0] = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
+        part[(((long)b * GN_SPLIT + sp) * C + c) * 2 + 1] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+    }
+}
+// fwd: stats[b][c] = (mean, rstd);   bwd: sums[b][c] = (sum dz, sum dz*xhat)
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* out, int Tn, int C, int B, float eps, int fwd) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C) return;
+    const int b = (int)(idx / C), c = (int)(idx - (long)b * C);
+    float s0 = 0.f, s1 = 0.f;
+    for (int sp = 0; sp < GN_SPLIT; ++sp) { s0 += part[(((long)b * GN_SPLIT + sp) * C + c) * 2]; s1 += part[(((long)b * GN_SPLIT + sp) * C + c) * 2 + 1]; }
+    if (fwd) {
+        const float mean = s0 / Tn;
+        float var = s1 / Tn - mean * mean; var = var > 0.f ? var : 0.f;
+        out[idx * 2] = mean; out[idx * 2 + 1] = rsqrtf(var + eps);
+    } else { out[idx * 2] = s0; out[idx * 2 + 1] = s1; }
+}
+template <typename T>
+__global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, long n4, int Tn, int C) {
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= n4) return;
+    const long e = i4 * 4; const int c = (int)(e % C); const long bt = e / C; const int b = (int)(bt / Tn);
+    f32x4 v = ld4(x + e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* st = stats + ((long)b * C + c + k) * 2;
+        v[k] = gelu_f((v[k] - st[0]) * st[1] * gamma[c + k] + beta[c + k]);
+    }
+    st4(y + e, v);
+}
+template <typename T>
+__global__ void gn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ sums, long n4, int Tn, int C) {
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= n4) return;
+    const long e = i4 * 4; const int c = (int)(e % C); const long bt = e / C; const int b = (int)(bt / Tn);
+    const f32x4 xv = ld4(x + e), dyv = ld4(dy + e);
+    f32x4 o;
+    const float invT = 1.f / Tn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* st = stats + ((long)b * C + c + k) * 2;
+        const float* sm = sums + ((long)b * C + c + k) * 2;
+        const float xh = (xv[k] - st[0]) * st[1], gam = gamma[c + k];
+        const float dz = dyv[k] * gelu_grad_f(xh * gam + beta[c + k]);
+        o[k] = st[1] * gam * (dz - sm[0] * invT - xh * sm[1] * invT);
+    }
+    st4(dx + e, o);
+}
+__global__ void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; ++b) { bsum += sums[((long)b * C + c) * 2]; g += sums[((long)b * C + c) * 2 + 1]; }
+    dgamma[c] = accumulate ? dgamma[c] + g : g;
+    dbeta[c] = accumulate ? dbeta[c] + bsum : bsum;
+}
+
+template <typename T> __global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = ld4(x + 4 * i);
+    v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
+    st4(y + 4 * i, v);
+}
+template <typename T> __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = ld4(x + 4 * i);
+    f32x4 d = ld4(dy + 4 * i);
+    d[0] *= gelu_grad_f(v[0]); d[1] *= gelu_grad_f(v[1]); d[2] *= gelu_grad_f(v[2]); d[3] *= gelu_grad_f(v[3]);
+    st4(dx + 4 * i, d);
+}
+
+static LnP pack(const tav_ln_args* a) {
+    LnP p;
+    p.x = a->x; p.gamma = a->gamma; p.beta = a->beta; p.y_f32 = a->y_f32; p.y_lp = a->y_lp; p.mean = a->mean; p.rstd = a->rstd;
+    p.dy = a->dy; p.dx_add = a->dx_add; p.dx_f32 = a->dx_f32; p.dx_lp = a->dx_lp; p.partials = a->partials;
+    p.rows = a->rows; p.W = (int)a->W; p.ld_x = a->ld_x; p.ld_y = a->ld_y; p.ld_dy = a->ld_dy; p.ld_dx = a->ld_dx; p.eps = a->eps; p.act = a->act;
+    return p;
+}
+
+}  // namespace tav
+using namespace tav;
+
+extern "C" int tav_ln_bwd_partials(int64_t rows) { return ln_blocks(rows); }
+
+extern "C" int tav_ln_fwd(const tav_ln_args* a, void* stream) {
+    if (!a || !a->x || !a->gamma || !a->beta || (!a->y_f32 && !a->y_lp)) return TAV_ERR_NULL;
+    if (a->rows <= 0 || a->W <= 0 || a->W > 1024 || a->W % 4) return TAV_ERR_SHAPE;
+    if (a->ld_x % 4 || a->ld_y % 4) return TAV_ERR_ALIGN;
+    const LnP p = pack(a);
+    hipStream_t st = (hipStream_t)stream;
+    const long want = (a->rows + 3) / 4;
+    dim3 grid((unsigned)(want < 2048 ? want : 2048)), block(256);
+    const bool lp_bf16 = a->y_lp && a->lp_dtype == TAV_BF16;
+    if (a->x_dtype == TAV_F32) {
+        if (lp_bf16) hipLaunchKernelGGL((ln_fwd_kernel<float, bf16>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, block, 0, st, p);
+    } else if (a->x_dtype == TAV_BF16) {
+        if (lp_bf16) hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ln_fwd_kernel<bf16, float>), grid, block, 0, st, p);
+    } else return TAV_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
+    if (!a || !a->x || !a->gamma || !a->dy || !a->mean || !a->rstd || (!a->dx_f32 && !a->dx_lp)) return TAV_ERR_NULL;
+    if (a->act == 1 && !a->beta) return TAV_ERR_NULL;
+    if ((a->dgamma || a->dbeta) && !a->partials) return TAV_ERR_NULL;
+    if (a->rows <= 0 || a->W <= 0 || a->W > 1024 || a->W % 4) return TAV_ERR_SHAPE;
+    if (a->ld_x % 4 || a->ld_dy % 4 || a->ld_dx % 4) return TAV_ERR_ALIGN;
+    LnP p = pack(a);
+    if (!a->dgamma && !a->dbeta) p.partials = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = ln_blocks(a->rows);
+    dim3 grid(nb), block(256);
+    const bool lp_bf16 = a->dx_lp && a->lp_dtype == TAV_BF16;
+#define TAV_LN_BWD(TX, TDY)                                                                              \
+    do {                                                                                                 \
+        if (lp_bf16) hipLaunchKernelGGL((ln_bwd_kernel<TX, TDY, bf16>), grid, block, 0, st, p);           \
+        else hipLaunchKernelGGL((ln_bwd_kernel<TX, TDY, float>), grid, block, 0, st, p);                  \
+    } while (0)
+    if (a->x_dtype == TAV_F32 && a->dy_dtype == TAV_F32) TAV_LN_BWD(float, float);
+    else if (a->x_dtype == TAV_F32 && a->dy_dtype == TAV_BF16) TAV_LN_BWD(float, bf16);
+    else if (a->x_dtype == TAV_BF16 && a->dy_dtype == TAV_F32) TAV_LN_BWD(bf16, float);
+    else if (a->x_dtype == TAV_BF16 && a->dy_dtype == TAV_BF16) TAV_LN_BWD(bf16, bf16);
+    else return TAV_ERR_DTYPE;
+#undef TAV_LN_BWD
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    if (p.partials) {
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 256)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
+                           a->accumulate_params);
+        e = (int)hipGetLastError();
+    }
+    return e;
+}
+
+extern "C" int tav_gn_workspace_floats(int64_t B, int64_t C) { return (int)(B * GN_SPLIT * C * 2 + B * C * 2); }
+
+extern "C" int tav_gn_gelu_fwd(const void* x, void* y, int32_t dtype, const float* gamma, const float* beta, float* stats, float* workspace,
+                               int64_t B, int64_t T, int64_t C, float eps, void* stream) {
+    if (!x || !y || !gamma || !beta || !stats || !workspace) return TAV_ERR_NULL;
+    if (B <= 0 || T <= 0 || C <= 0 || C % 64) return TAV_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(C / 64), GN_SPLIT, (unsigned)B);
+    const long n4 = B * T * C / 4;
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_stats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, stats, workspace, (int)T, (int)C);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, gamma, beta, stats, workspace, (int)T, (int)C);
+    else return TAV_ERR_DTYPE;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(tav_cdiv(B * C, 256)), dim3(256), 0, st, workspace, stats, (int)T, (int)C, (int)B, eps, 1);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, stats, n4, (int)T, (int)C);
+    else hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, stats, n4, (int)T, (int)C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_gn_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, const float* gamma, const float* beta, const float* stats,
+                               float* workspace, float* dgamma, float* dbeta, int64_t B, int64_t T, int64_t C, int32_t accumulate, void* stream) {
+    if (!x || !dy || !dx || !gamma || !beta || !stats || !workspace || !dgamma || !dbeta) return TAV_ERR_NULL;
+    if (B <= 0 || T <= 0 || C <= 0 || C % 64) return TAV_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(C / 64), GN_SPLIT, (unsigned)B);
+    const long n4 = B * T * C / 4;
+    float* sums = workspace + B * GN_SPLIT * C * 2;
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_stats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, workspace, (int)T, (int)C);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, gamma, beta, stats, workspace, (int)T, (int)C);
+    else return TAV_ERR_DTYPE;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(tav_cdiv(B * C, 256)), dim3(256), 0, st, workspace, sums, (int)T, (int)C, (int)B, 0.f, 0);
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(tav_cdiv(C, 256)), dim3(256), 0, st, sums, dgamma, dbeta, (int)B, (int)C, accumulate);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, gamma, beta, stats, sums, n4, (int)T, (int)C);
+    else hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, gamma, beta, stats, sums, n4, (int)T, (int)C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_gelu_fwd(const void* x, void* y, int32_t dtype, int64_t n, void* stream) {
+    if (!x || !y) return TAV_ERR_NULL;
+    if (n <= 0 || n % 4) return TAV_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16>), dim3(tav_cdiv(n / 4, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n / 4);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3(tav_cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)x, (float*)y, n / 4);
+    else return TAV_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+extern "C" int tav_gelu_bwd(const void* x, const void* dy, void* dx, int32_t dtype, int64_t n, void* stream) {
+    if (!x || !dy || !dx) return TAV_ERR_NULL;
+    if (n <= 0 || n % 4) return TAV_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(tav_cdiv(n / 4, 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, n / 4);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(tav_cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, n / 4);
+    else return TAV_ERR_DTYPE;
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,9 @@
+// Internal glue: the public ABI (include/tavhip.h) plus launch helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/tavhip.h"
+
+#define TAV_ABI_VERSION 1
+
+static inline int tav_last_error() { return (int)hipGetLastError(); }
+static inline unsigned tav_cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }

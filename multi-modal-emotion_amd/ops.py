@@ -1,0 +1,418 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw pointers + the current HIP stream.
+
+No arithmetic happens here; torch is used for device memory and streams only.  Scratch buffers are cached per
+(name, stream) so that concurrent branches on different HIP streams never share a workspace.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import check, dt, lib, ptr, stream
+
+_ws = {}
+
+
+def workspace(name, nfloats, device):
+    key = (name, torch.cuda.current_stream().cuda_stream, str(device))
+    t = _ws.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def clear_workspaces():
+    _ws.clear()
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None, want_pre=False, out=None,
+            accumulate=False, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
+            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None):
+    """C = epi(alpha * A @ B^T).  Plain use: a [M,K], b [N,K] contiguous.  Strided/batched use: pass sizes/strides."""
+    if M is None:
+        M, K = a.shape[-2], a.shape[-1]
+        N = b.shape[-2]
+        lda, ldb = a.stride(-2), b.stride(-2)
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty(out_shape or (M, N), dtype=out_dtype, device=a.device)
+    if ldc is None:
+        ldc = out.stride(-2)
+    pre = torch.empty_like(out) if want_pre else None
+    g = L.GemmNTArgs()
+    g.A, g.B, g.C, g.C_pre = ptr(a), ptr(b), ptr(out), ptr(pre)
+    g.bias, g.gelu_in, g.resid = ptr(bias), ptr(gelu_in), ptr(resid)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc, g.ld_pre = lda, ldb, ldc, ldc
+    g.ld_gelu_in = gelu_in.stride(-2) if gelu_in is not None else 0
+    g.ld_resid = resid.stride(-2) if resid is not None else 0
+    g.nzb, g.nzg = nzb, nzg
+    g.a_zb, g.a_zg, g.b_zb, g.b_zg, g.c_zb, g.c_zg, g.bias_zg = a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg
+    g.in_dtype, g.out_dtype, g.act, g.accumulate, g.alpha = dt(a), dt(out), act, int(accumulate), alpha
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if resid is not None:
+        assert resid.dtype == torch.float32
+    if gelu_in is not None:
+        assert gelu_in.dtype == a.dtype
+    check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
+    return (out, pre) if want_pre else out
+
+
+def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb=None, rows_per_batch=None, nbatch=1,
+            a_zb=0, b_zb=0, perm_inner=0, perm_outer=0, scale=1.0, out_shape=None):
+    """out[n1][perm(n2)] (+)= sum_tokens A[t][n1] * B[t][n2]  (weight gradient)."""
+    if N1 is None:
+        N1, N2 = a.shape[-1], b.shape[-1]
+        rows_per_batch = a.shape[-2]
+        lda, ldb = a.stride(-2), b.stride(-2)
+    cr, ns = C.c_int32(), C.c_int32()
+    check(lib().tav_gemm_tn_splits(N1, N2, rows_per_batch, nbatch, C.byref(cr), C.byref(ns)), "gemm_tn_splits")
+    slabs = workspace("tn_slabs", ns.value * N1 * N2, a.device)
+    if out is None:
+        out = torch.empty(out_shape or (N1, N2), dtype=torch.float32, device=a.device)
+    g = L.GemmTNArgs()
+    g.A, g.B, g.slabs, g.out = ptr(a), ptr(b), ptr(slabs), ptr(out)
+    g.N1, g.N2, g.lda, g.ldb = N1, N2, lda, ldb
+    g.rows_per_batch, g.nbatch, g.a_zb, g.b_zb = rows_per_batch, nbatch, a_zb, b_zb
+    g.chunk_rows, g.nsplit, g.perm_inner, g.perm_outer = cr.value, ns.value, perm_inner, perm_outer
+    g.dtype, g.accumulate, g.scale = dt(a), int(accumulate), scale
+    assert a.dtype == b.dtype
+    check(lib().tav_gemm_tn(C.byref(g), stream()), "gemm_tn")
+    return out
+
+
+def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):
+    if M is None:
+        M, N, ld = x.shape[-2], x.shape[-1], x.stride(-2)
+    nparts = max(1, min(256, (M + 255) // 256))
+    part = workspace("colsum", nparts * N, x.device)
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(lib().tav_colsum(ptr(x), dt(x), M, N, ld, ptr(part), nparts, ptr(out), int(accumulate), stream()), "colsum")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale):
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(o)
+    a.key_mask, a.lse, a.corr = ptr(key_mask), ptr(lse), ptr(corr)
+    a.B, a.S, a.nheads = B, S, nheads
+    a.ld_q, a.ld_k, a.ld_v, a.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
+    a.dtype, a.mask_mode, a.scale = dt(q), mask_mode, scale
+    return a
+
+
+def attn_fwd(q, k, v, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125):
+    """q,k,v: [B*S, >=nheads*64] views (row stride arbitrary).  Returns o [B*S, nheads*64], lse, corr."""
+    H = nheads * 64
+    o = torch.empty(B * S, H, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, nheads, S, dtype=torch.float32, device=q.device)
+    corr = torch.empty(B, nheads, 64, dtype=torch.float32, device=q.device) if mask_mode == 2 else None
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale)
+    check(lib().tav_attn_fwd(C.byref(a), stream()), "attn_fwd")
+    return o, lse, corr
+
+
+def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, dqkv=None):
+    """Returns dqkv [B*S, 3H] (dq | dk | dv), the layout the fused QKV projection's backward consumes."""
+    H = nheads * 64
+    if dqkv is None:
+        dqkv = torch.empty(B * S, 3 * H, dtype=q.dtype, device=q.device)
+    dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    delta = workspace("attn_delta", B * nheads * S, q.device)
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale)
+    a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
+    a.ld_do, a.ld_dq, a.ld_dk, a.ld_dv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
+    check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------- layer norm
+def ln_fwd(x, gamma, beta, eps, *, want_f32=True, lp_dtype=None, act=0):
+    """x [rows, W] f32 or bf16.  Returns (y_f32 | None, y_lp | None, mean, rstd)."""
+    rows, W = x.shape
+    y32 = torch.empty(rows, W, dtype=torch.float32, device=x.device) if want_f32 else None
+    ylp = torch.empty(rows, W, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    a = L.LnArgs()
+    a.x, a.x_dtype, a.gamma, a.beta = ptr(x), dt(x), ptr(gamma), ptr(beta)
+    a.y_f32, a.y_lp, a.lp_dtype = ptr(y32), ptr(ylp), dt(lp_dtype) if lp_dtype is not None else 0
+    a.mean, a.rstd = ptr(mean), ptr(rstd)
+    a.rows, a.W, a.ld_x, a.ld_y, a.eps, a.act = rows, W, x.stride(0), W, eps, act
+    check(lib().tav_ln_fwd(C.byref(a), stream()), "ln_fwd")
+    return y32, ylp, mean, rstd
+
+
+def ln_bwd(dy, x, gamma, beta, mean, rstd, *, dx_add=None, want_f32=True, lp_dtype=None, act=0, param_grads=True):
+    """Returns (dx_f32 | None, dx_lp | None, dgamma, dbeta)."""
+    rows, W = x.shape
+    dx32 = torch.empty(rows, W, dtype=torch.float32, device=x.device) if want_f32 else None
+    dxlp = torch.empty(rows, W, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
+    dgamma = dbeta = part = None
+    if param_grads:
+        dgamma = torch.empty(W, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(W, dtype=torch.float32, device=x.device)
+        part = workspace("ln_part", lib().tav_ln_bwd_partials(rows) * 2 * W, x.device)
+    a = L.LnArgs()
+    a.x, a.x_dtype, a.gamma, a.beta = ptr(x), dt(x), ptr(gamma), ptr(beta)
+    a.mean, a.rstd = ptr(mean), ptr(rstd)
+    a.dy, a.dy_dtype, a.dx_add = ptr(dy), dt(dy), ptr(dx_add)
+    a.dx_f32, a.dx_lp, a.lp_dtype = ptr(dx32), ptr(dxlp), dt(lp_dtype) if lp_dtype is not None else 0
+    a.dgamma, a.dbeta, a.partials, a.accumulate_params = ptr(dgamma), ptr(dbeta), ptr(part), 0
+    a.rows, a.W, a.ld_x, a.ld_dy, a.ld_dx, a.act = rows, W, x.stride(0), dy.stride(0), W, act
+    check(lib().tav_ln_bwd(C.byref(a), stream()), "ln_bwd")
+    return dx32, dxlp, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------- casts & small ops
+def cast_weight(w, dtype, *, want_t=True, want_n=True):
+    """f32 [R,C] parameter -> (copy in dtype [R,C], transposed copy [C,R])."""
+    R, Cc = w.shape
+    n = torch.empty(R, Cc, dtype=dtype, device=w.device) if want_n else None
+    t = torch.empty(Cc, R, dtype=dtype, device=w.device) if want_t else None
+    check(lib().tav_cast_weight(ptr(w), R, Cc, ptr(n), ptr(t), dt(dtype), stream()), "cast_weight")
+    return n, t
+
+
+def cast_conv_weight(w, dtype):
+    co, ci, k = w.shape
+    n = torch.empty(co, k * ci, dtype=dtype, device=w.device)
+    t = torch.empty(k * ci, co, dtype=dtype, device=w.device)
+    check(lib().tav_cast_conv_weight(ptr(w), co, ci, k, ptr(n), ptr(t), dt(dtype), stream()), "cast_conv_weight")
+    return n, t
+
+
+def cast2d(x, dtype, out=None):
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty(R, Cc, dtype=dtype, device=x.device)
+    check(lib().tav_cast2d(ptr(x), dt(x), x.stride(0), ptr(out), dt(out), out.stride(0), R, Cc, stream()), "cast2d")
+    return out
+
+
+def add_f32(a, b, *, want_f32=True, lp_dtype=None):
+    y = torch.empty_like(a) if want_f32 else None
+    ylp = torch.empty(a.shape, dtype=lp_dtype, device=a.device) if lp_dtype is not None else None
+    check(lib().tav_add_f32(ptr(a), ptr(b), ptr(y), ptr(ylp), dt(lp_dtype) if lp_dtype is not None else 0, a.numel(), stream()), "add_f32")
+    return y, ylp
+
+
+def zeros_f32(shape, device):
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib().tav_fill_f32(ptr(t), 0.0, t.numel(), stream()), "fill")
+    return t
+
+
+def embed_add_fwd(x, ids, table):
+    rows, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().tav_embed_add_fwd(ptr(x), ptr(ids), ptr(table), ptr(out), rows, W, table.shape[0], stream()), "embed_add_fwd")
+    return out
+
+
+def embed_add_bwd(dy, ids, ntable):
+    rows, W = dy.shape
+    parts = lib().tav_embed_add_bwd_parts(rows)
+    part = workspace("embed_part", parts * ntable * W, dy.device)
+    d = torch.empty(ntable, W, dtype=torch.float32, device=dy.device)
+    check(lib().tav_embed_add_bwd(ptr(dy), ptr(ids), ptr(d), ptr(part), rows, W, ntable, 0, stream()), "embed_add_bwd")
+    return d
+
+
+def text_embed_fwd(ids, word, pos, type_, gamma, beta, eps, pad_id, *, want_f32=True, lp_dtype=None):
+    B, S = ids.shape
+    W = word.shape[1]
+    dev = ids.device
+    pre = torch.empty(B * S, W, dtype=torch.float32, device=dev)
+    pos_ids = torch.empty(B, S, dtype=torch.int64, device=dev)
+    y32 = torch.empty(B * S, W, dtype=torch.float32, device=dev) if want_f32 else None
+    ylp = torch.empty(B * S, W, dtype=lp_dtype, device=dev) if lp_dtype is not None else None
+    mean = torch.empty(B * S, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * S, dtype=torch.float32, device=dev)
+    a = L.TextEmbedArgs()
+    a.ids, a.word, a.pos, a.type, a.gamma, a.beta = ptr(ids), ptr(word), ptr(pos), ptr(type_), ptr(gamma), ptr(beta)
+    a.pre, a.pos_ids, a.y_f32, a.y_lp = ptr(pre), ptr(pos_ids), ptr(y32), ptr(ylp)
+    a.lp_dtype = dt(lp_dtype) if lp_dtype is not None else 0
+    a.mean, a.rstd = ptr(mean), ptr(rstd)
+    a.B, a.S, a.W, a.vocab, a.max_pos, a.pad_id, a.eps = B, S, W, word.shape[0], pos.shape[0], pad_id, eps
+    check(lib().tav_text_embed_fwd(C.byref(a), stream()), "text_embed_fwd")
+    return y32, ylp, pre, pos_ids, mean, rstd
+
+
+def scatter_add_rows(d, idx, ntable):
+    rows, W = d.shape
+    out = zeros_f32((ntable, W), d.device)
+    check(lib().tav_scatter_add_rows(ptr(d), ptr(idx), ptr(out), rows, W, ntable, stream()), "scatter_add_rows")
+    return out
+
+
+def gather_rows(table, idx):
+    rows, W = idx.numel(), table.shape[1]
+    out = torch.empty(rows, W, dtype=torch.float32, device=table.device)
+    check(lib().tav_gather_rows(ptr(table), ptr(idx), ptr(out), rows, W, stream()), "gather_rows")
+    return out
+
+
+def mask_to_index(mask_bool, keep_value, nkeep):
+    B, n = mask_bool.shape
+    m8 = mask_bool.view(torch.uint8) if mask_bool.dtype == torch.bool else mask_bool
+    idx = torch.empty(B, nkeep, dtype=torch.int32, device=mask_bool.device)
+    counts = torch.empty(B, dtype=torch.int32, device=mask_bool.device)
+    check(lib().tav_mask_to_index(ptr(m8), int(keep_value), ptr(idx), ptr(counts), B, n, nkeep, stream()), "mask_to_index")
+    return idx, counts
+
+
+def patchify(video, keep_idx, dtype):
+    B, F, Cc, H, W = video.shape
+    assert Cc == 3 and video.dtype == torch.float32 and video.is_contiguous()
+    nkeep = keep_idx.shape[1]
+    out = torch.empty(B * nkeep, 1536, dtype=dtype, device=video.device)
+    check(lib().tav_patchify(ptr(video), ptr(keep_idx), ptr(out), dt(dtype), B, F, H, W, nkeep, stream()), "patchify")
+    return out
+
+
+def mean_pool_fwd(x, B, S):
+    W = x.shape[-1]
+    y = torch.empty(B, W, dtype=torch.float32, device=x.device)
+    check(lib().tav_mean_pool_fwd(ptr(x), ptr(y), B, S, W, stream()), "mean_pool_fwd")
+    return y
+
+
+def mean_pool_bwd(dy, B, S, *, want_f32=True, lp_dtype=None):
+    W = dy.shape[-1]
+    dx = torch.empty(B * S, W, dtype=torch.float32, device=dy.device) if want_f32 else None
+    dxlp = torch.empty(B * S, W, dtype=lp_dtype, device=dy.device) if lp_dtype is not None else None
+    check(lib().tav_mean_pool_bwd(ptr(dy), ptr(dx), ptr(dxlp), dt(lp_dtype) if lp_dtype is not None else 0, B, S, W, stream()), "mean_pool_bwd")
+    return dx, dxlp
+
+
+def head_fwd(x, W, b):
+    B, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(lib().tav_head_fwd(ptr(x), ptr(W), ptr(b), ptr(y), B, K, N, stream()), "head_fwd")
+    return y
+
+
+def head_bwd(x, W, dy, need_dx=True, need_db=True):
+    B, K = x.shape
+    N = W.shape[0]
+    dx = torch.empty(B, K, dtype=torch.float32, device=x.device) if need_dx else None
+    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if need_db else None
+    check(lib().tav_head_bwd(ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), B, K, N, 0, stream()), "head_bwd")
+    return dx, dW, db
+
+
+def tanh_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().tav_tanh_fwd(ptr(x), ptr(y), x.numel(), stream()), "tanh_fwd")
+    return y
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(y)
+    check(lib().tav_tanh_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), stream()), "tanh_bwd")
+    return dx
+
+
+def cross_entropy(logits, target, class_weight=None, grad_scale=1.0, want_grad=True):
+    B, Cn = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlog = torch.empty_like(logits) if want_grad else None
+    check(lib().tav_cross_entropy(ptr(logits), ptr(target), ptr(class_weight), ptr(loss), ptr(dlog), B, Cn, grad_scale, stream()), "cross_entropy")
+    return loss, dlog
+
+
+def dropout_fwd(x, p, seed, offset):
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().tav_dropout_fwd(ptr(x), ptr(y), ptr(mask), x.numel(), p, seed, offset, stream()), "dropout_fwd")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, p):
+    dx = torch.empty_like(dy)
+    check(lib().tav_dropout_bwd(ptr(dy), ptr(mask), ptr(dx), dy.numel(), p, stream()), "dropout_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- audio front-end
+def conv0_fwd(wave, w, bias, T_out, stride, dtype):
+    B, T_in = wave.shape
+    Cc, K = w.shape[0], w.shape[-1]
+    y = torch.empty(B, T_out, Cc, dtype=dtype, device=wave.device)
+    check(lib().tav_conv0_fwd(ptr(wave), ptr(w), ptr(bias), ptr(y), dt(dtype), B, T_in, T_out, Cc, K, stride, stream()), "conv0_fwd")
+    return y
+
+
+def conv0_bwd_w(wave, dy, K, stride, want_bias):
+    B, T_in = wave.shape
+    _, T_out, Cc = dy.shape
+    part = workspace("conv0_part", lib().tav_conv0_bwd_partials(B, T_out, Cc, K), wave.device)
+    dw = torch.empty(Cc, 1, K, dtype=torch.float32, device=wave.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=wave.device) if want_bias else None
+    check(lib().tav_conv0_bwd_w(ptr(wave), ptr(dy), dt(dy), ptr(dw), ptr(db), ptr(part), B, T_in, T_out, Cc, K, stride, 0, stream()), "conv0_bwd_w")
+    return dw, db
+
+
+def gn_gelu_fwd(x, gamma, beta, eps):
+    B, T, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(B, Cc, 2, dtype=torch.float32, device=x.device)
+    wsb = workspace("gn_ws", lib().tav_gn_workspace_floats(B, Cc), x.device)
+    check(lib().tav_gn_gelu_fwd(ptr(x), ptr(y), dt(x), ptr(gamma), ptr(beta), ptr(stats), ptr(wsb), B, T, Cc, eps, stream()), "gn_gelu_fwd")
+    return y, stats
+
+
+def gn_gelu_bwd(x, dy, gamma, beta, stats):
+    B, T, Cc = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    wsb = workspace("gn_ws", lib().tav_gn_workspace_floats(B, Cc), x.device)
+    check(lib().tav_gn_gelu_bwd(ptr(x), ptr(dy), ptr(dx), dt(x), ptr(gamma), ptr(beta), ptr(stats), ptr(wsb), ptr(dg), ptr(db), B, T, Cc, 0, stream()), "gn_gelu_bwd")
+    return dx, dg, db
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().tav_gelu_bwd(ptr(x), ptr(dy), ptr(dx), dt(x), x.numel(), stream()), "gelu_bwd")
+    return dx
+
+
+def col2im_1d(dcol, B, T_in, T_out, Cc, K, stride, pre_act=None):
+    dx = torch.empty(B, T_in, Cc, dtype=dcol.dtype, device=dcol.device)
+    check(lib().tav_col2im_1d(ptr(dcol), ptr(dx), ptr(pre_act), dt(dcol), B, T_in, T_out, Cc, K, stride, stream()), "col2im_1d")
+    return dx
+
+
+def group_pad(x, B, T, H, G, pad_l, pad_r, dtype):
+    xg = torch.empty(B, G, pad_l + T + pad_r, H // G, dtype=dtype, device=x.device)
+    check(lib().tav_group_pad(ptr(x), dt(x), ptr(xg), dt(dtype), B, T, H, G, pad_l, pad_r, stream()), "group_pad")
+    return xg
+
+
+def weight_norm_fwd(v, g, dtype):
+    H, Cg, K = v.shape
+    norms = torch.empty(K, dtype=torch.float32, device=v.device)
+    part = workspace("wn_part", lib().tav_weight_norm_partials(H, Cg) * K, v.device)
+    G = H // Cg
+    w = torch.empty(G, Cg, K * Cg, dtype=dtype, device=v.device)
+    wf = torch.empty(G, Cg, K * Cg, dtype=dtype, device=v.device)
+    check(lib().tav_weight_norm_fwd(ptr(v), ptr(g), ptr(norms), ptr(part), ptr(w), ptr(wf), dt(dtype), H, Cg, K, stream()), "weight_norm_fwd")
+    return w, wf, norms
+
+
+def weight_norm_bwd(v, g, norms, dw_gemm):
+    H, Cg, K = v.shape
+    wsb = workspace("wn_bwd", H * Cg * K + lib().tav_weight_norm_partials(H, Cg) * K + K, v.device)
+    dv = torch.empty_like(v)
+    dg = torch.empty(K, dtype=torch.float32, device=v.device)
+    check(lib().tav_weight_norm_bwd(ptr(v), ptr(g), ptr(norms), ptr(dw_gemm), ptr(wsb), ptr(dv), ptr(dg), H, Cg, K, 0, stream()), "weight_norm_bwd")
+    return dv, dg

@@ -1,0 +1,355 @@
+"""Per-kernel numerical checks of libtavhip against plain PyTorch references of the same op (run on the GPU).
+
+Each check returns (name, max_abs_err, tolerance, ok).  Used by tests/test_kernels_gpu.py (asserts) and by
+tools/gpu_kernel_check.py (prints a table without stopping at the first failure).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+import tav_amd.ops as ops
+
+DEV = "cuda"
+
+
+def _rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _res(name, got, ref, tol):
+    got = got.float()
+    ref = ref.float()
+    err = (got - ref).abs().max().item()
+    den = ref.abs().max().item() + 1e-12
+    ok = bool(err <= tol * max(den, 1.0)) and bool(torch.isfinite(got).all())
+    return (name, err / max(den, 1.0), tol, ok)
+
+
+def tol_for(dtype):
+    return 2e-2 if dtype == torch.bfloat16 else 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def check_gemm_nt(dtype, M=300, N=256, K=128, bias=True, act=0, resid=True, pre=False, out_f32=False):
+    a = _rnd(M, K, dtype=dtype, seed=1)
+    b = _rnd(N, K, dtype=dtype, scale=0.1, seed=2)
+    bi = _rnd(N, seed=3) if bias else None
+    r = _rnd(M, N, seed=4) if resid else None
+    out_dtype = torch.float32 if (out_f32 or dtype == torch.float32) else dtype
+    res = ops.gemm_nt(a, b, bias=bi, act=act, resid=r, want_pre=pre, out_dtype=out_dtype)
+    out, p = res if pre else (res, None)
+    ref = a.float() @ b.float().t()
+    if bias:
+        ref = ref + bi
+    ref_pre = ref
+    if act == 1:
+        ref = F.gelu(ref)
+    if resid:
+        ref = ref + r
+    tol = tol_for(dtype if out_dtype != torch.float32 else torch.float32) if dtype == torch.float32 else (1e-2 if out_dtype == torch.bfloat16 else 2e-3)
+    rs = [_res(f"gemm_nt[{dtype},M{M},N{N},K{K},b{int(bias)},a{act},r{int(resid)},f32out{int(out_f32)}]", out, ref, tol)]
+    if pre:
+        rs.append(_res("gemm_nt.pre", p, ref_pre, tol))
+    return rs
+
+
+def check_gemm_nt_gelu_bwd(dtype, M=200, N=384, K=256):
+    a = _rnd(M, K, dtype=dtype, seed=5)
+    b = _rnd(N, K, dtype=dtype, scale=0.1, seed=6)
+    u = _rnd(M, N, dtype=dtype, seed=7)
+    out = ops.gemm_nt(a, b, gelu_in=u)
+    uu = u.float().requires_grad_(True)
+    (gr,) = torch.autograd.grad(F.gelu(uu).sum(), uu)
+    ref = (a.float() @ b.float().t()) * gr
+    return [_res(f"gemm_nt.gelu_bwd[{dtype}]", out, ref, 1e-2 if dtype == torch.bfloat16 else 2e-5)]
+
+
+def check_gemm_tn(dtype, M=1000, N1=256, N2=384, nbatch=1):
+    a = _rnd(nbatch * M, N1, dtype=dtype, seed=8)
+    b = _rnd(nbatch * M, N2, dtype=dtype, seed=9)
+    out = ops.gemm_tn(a, b, N1=N1, N2=N2, lda=N1, ldb=N2, rows_per_batch=M, nbatch=nbatch, a_zb=M * N1, b_zb=M * N2)
+    ref = a.float().t() @ b.float()
+    return [_res(f"gemm_tn[{dtype},M{M},N1{N1},N2{N2},nb{nbatch}]", out, ref, 2e-3 if dtype == torch.bfloat16 else 2e-5)]
+
+
+def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
+    """Conv1d(C,C,k,stride s) on channels-last activations as an NT GEMM over overlapping rows + its gradients."""
+    T_out = (T_in - k) // s + 1
+    x = _rnd(B, T_in, Cc, dtype=dtype, seed=10)
+    w = _rnd(Cc, Cc, k, scale=0.1, seed=11)              # nn.Conv1d layout [co][ci][k], f32 parameter
+    wn, wt = ops.cast_conv_weight(w, dtype)
+    y, pre = ops.gemm_nt(x, wn, act=1, want_pre=True, M=T_out, N=Cc, K=k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Cc,
+                         nzb=B, a_zb=T_in * Cc, c_zb=T_out * Cc, out_shape=(B, T_out, Cc))
+    xr = x.float().permute(0, 2, 1).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    pre_ref = F.conv1d(xr, wr if dtype == torch.float32 else wr.to(dtype).float(), stride=s)
+    y_ref = F.gelu(pre_ref)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    rs = [_res(f"conv_gemm.fwd[{dtype}]", y, y_ref.permute(0, 2, 1), tol)]
+    dy = _rnd(B, T_out, Cc, dtype=dtype, seed=12)
+    y_ref.backward(dy.float().permute(0, 2, 1))
+    du = ops.gelu_bwd(pre, dy)
+    dcol = ops.gemm_nt(du.view(B * T_out, Cc), wt, out_shape=(B * T_out, k * Cc))
+    dx = ops.col2im_1d(dcol, B, T_in, T_out, Cc, k, s)
+    rs.append(_res(f"conv_gemm.dx[{dtype}]", dx, xr.grad.permute(0, 2, 1), tol))
+    dw = ops.gemm_tn(du, x, N1=Cc, N2=k * Cc, lda=Cc, ldb=s * Cc, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Cc,
+                     b_zb=T_in * Cc, perm_inner=Cc, perm_outer=k, out_shape=(Cc, Cc, k))
+    rs.append(_res(f"conv_gemm.dw[{dtype}]", dw, wr.grad, 3e-3 if dtype == torch.bfloat16 else 2e-5))
+    return rs
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, mask, mode, scale):
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    if mode == 1:
+        s = s + mask[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    if mode == 2:
+        p = p + mask[:, None, None, :]
+    return torch.einsum("bhqk,bhkd->bhqd", p, v)
+
+
+def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True):
+    H = nh * 64
+    qkv = _rnd(B * S, 3 * H, dtype=dtype, seed=20 + mode)
+    mask = None
+    if mode == 1:
+        mask = torch.zeros(B, S, device=DEV)
+        mask[:, S - 37:] = torch.finfo(torch.float32).min
+    if mode == 2:
+        mask = torch.zeros(B, S, device=DEV)
+        mask[:, : S // 3] = -0.5
+        mask[:, S // 3: S // 2] = 2.0
+        mask[0, S // 2:] = 1.0
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    o, lse, corr = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode)
+
+    def heads(t):
+        return t.float().reshape(B, S, nh, 64).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+
+    qr, kr, vr = heads(q), heads(k), heads(v)
+    o_ref = _attn_ref(qr, kr, vr, mask, mode, 0.125)
+    tol = 2e-2 if dtype == torch.bfloat16 else 5e-5
+    rs = [_res(f"attn.fwd[{dtype},mode{mode},S{S}]", o, o_ref.permute(0, 2, 1, 3).reshape(B * S, H), tol)]
+    if bwd:
+        do = _rnd(B * S, H, dtype=dtype, seed=30 + mode)
+        o_ref.backward(do.float().reshape(B, S, nh, 64).permute(0, 2, 1, 3))
+        dqkv = ops.attn_bwd(q, k, v, o, do, lse, corr, B, S, nh, key_mask=mask, mask_mode=mode)
+
+        def flat(t):
+            return t.permute(0, 2, 1, 3).reshape(B * S, H)
+
+        tolb = 3e-2 if dtype == torch.bfloat16 else 1e-4
+        rs.append(_res(f"attn.dq[{dtype},mode{mode}]", dqkv[:, :H], flat(qr.grad), tolb))
+        rs.append(_res(f"attn.dk[{dtype},mode{mode}]", dqkv[:, H:2 * H], flat(kr.grad), tolb))
+        rs.append(_res(f"attn.dv[{dtype},mode{mode}]", dqkv[:, 2 * H:], flat(vr.grad), tolb))
+    return rs
+
+
+# ------------------------------------------------------------------------------------------------ layer norm
+def check_layernorm(x_dtype, W=768, rows=333, act=0):
+    x = _rnd(rows, W, dtype=x_dtype, seed=40)
+    gamma = 1.0 + 0.1 * _rnd(W, seed=41)
+    beta = 0.1 * _rnd(W, seed=42)
+    y32, ylp, mean, rstd = ops.ln_fwd(x, gamma, beta, 1e-5, want_f32=True, lp_dtype=torch.bfloat16, act=act)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (W,), gr, br, 1e-5)
+    if act:
+        ref = F.gelu(ref)
+    rs = [_res(f"ln.fwd[{x_dtype},W{W},act{act}]", y32, ref, 2e-5), _res("ln.fwd.lp", ylp, ref, 1e-2)]
+    dy = _rnd(rows, W, seed=43)
+    add = _rnd(rows, W, seed=44)
+    ref.backward(dy)
+    dx32, dxlp, dg, db = ops.ln_bwd(dy, x, gamma, beta, mean, rstd, dx_add=add, want_f32=True, lp_dtype=torch.bfloat16, act=act)
+    rs += [_res("ln.dx", dx32, xr.grad + add, 5e-5), _res("ln.dx.lp", dxlp, xr.grad + add, 1e-2),
+           _res("ln.dgamma", dg, gr.grad, 1e-4), _res("ln.dbeta", db, br.grad, 1e-4)]
+    return rs
+
+
+# ------------------------------------------------------------------------------------------------ misc
+def check_cast_weight():
+    w = _rnd(300, 200, seed=50)
+    n, t = ops.cast_weight(w, torch.bfloat16)
+    return [_res("cast_weight.n", n, w.bfloat16(), 0.0), _res("cast_weight.t", t, w.bfloat16().t(), 0.0)]
+
+
+def check_colsum():
+    x = _rnd(1000, 768, dtype=torch.bfloat16, seed=51)
+    return [_res("colsum", ops.colsum(x), x.float().sum(0), 1e-5)]
+
+
+def check_text_embed(pad_id=1):
+    B, S, W, V = 3, 50, 768, 1000
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, V, (B, S), generator=g)
+    ids[:, S - 9:] = 1
+    ids = ids.to(DEV)
+    word, pos, typ = _rnd(V, W, seed=52), _rnd(S + 10, W, seed=53), _rnd(1, W, seed=54)
+    gamma, beta = 1 + 0.1 * _rnd(W, seed=55), 0.1 * _rnd(W, seed=56)
+    y32, _, pre, pos_ids, _, _ = ops.text_embed_fwd(ids, word, pos, typ, gamma, beta, 1e-5, pad_id)
+    if pad_id >= 0:
+        m = ids.ne(pad_id).int()
+        pid = (torch.cumsum(m, 1) * m).long() + pad_id
+    else:
+        pid = torch.arange(S, device=DEV)[None].expand(B, S)
+    ref = F.layer_norm(word[ids] + pos[pid] + typ[0], (W,), gamma, beta, 1e-5).reshape(B * S, W)
+    return [_res(f"text_embed[pad{pad_id}]", y32, ref, 2e-5), _res("text_embed.pos_ids", pos_ids.float(), pid.float(), 0.0)]
+
+
+def check_patchify(dtype=torch.float32):
+    B, Fr, H, W, nkeep = 2, 4, 32, 48, 5
+    video = _rnd(B, Fr, 3, H, W, seed=57)
+    ntok = (Fr // 2) * (H // 16) * (W // 16)
+    mask = torch.zeros(B, ntok, dtype=torch.bool)
+    mask[0, [0, 3, 4, 7, 11]] = True
+    mask[1, [1, 2, 5, 9, 10]] = True
+    mask = mask.to(DEV)
+    idx, counts = ops.mask_to_index(mask, True, nkeep)
+    patches = ops.patchify(video, idx, dtype)
+    wconv = _rnd(8, 3, 2, 16, 16, scale=0.05, seed=58)
+    emb = F.conv3d(video.permute(0, 2, 1, 3, 4), wconv, stride=(2, 16, 16)).flatten(2).transpose(1, 2)   # [B, ntok, 8]
+    ref = emb[mask].reshape(B * nkeep, 8)
+    got = patches.float() @ wconv.reshape(8, -1).t()
+    return [_res("patchify+gemm", got, ref, 1e-4), _res("mask_to_index.counts", counts.float(), torch.full((B,), float(nkeep), device=DEV), 0.0)]
+
+
+def check_pool_head_ce():
+    B, S, W = 3, 77, 768
+    x = _rnd(B * S, W, seed=60)
+    rs = [_res("mean_pool", ops.mean_pool_fwd(x, B, S), x.reshape(B, S, W).mean(1), 1e-5)]
+    dy = _rnd(B, W, seed=61)
+    dx, _ = ops.mean_pool_bwd(dy, B, S)
+    rs.append(_res("mean_pool.bwd", dx, (dy / S)[:, None, :].expand(B, S, W).reshape(B * S, W), 1e-6))
+    xh = _rnd(B, 3072, seed=62)
+    Wh, bh = _rnd(7, 3072, scale=0.05, seed=63), _rnd(7, seed=64)
+    y = ops.head_fwd(xh, Wh, bh)
+    xr, Wr, br = xh.clone().requires_grad_(True), Wh.clone().requires_grad_(True), bh.clone().requires_grad_(True)
+    yr = F.linear(xr, Wr, br)
+    rs.append(_res("head.fwd", y, yr, 1e-5))
+    tgt = torch.tensor([1, 6, 3], device=DEV)
+    cw = torch.rand(7, device=DEV) + 0.5
+    for weights in (None, cw):
+        loss, dlog = ops.cross_entropy(y, tgt, weights)
+        yl = y.clone().requires_grad_(True)
+        lr = F.cross_entropy(yl, tgt, weight=weights)
+        lr.backward()
+        rs.append(_res(f"ce.loss[w{weights is not None}]", loss, lr.reshape(1), 1e-5))
+        rs.append(_res(f"ce.dlogits[w{weights is not None}]", dlog, yl.grad, 1e-5))
+    dyh = _rnd(B, 7, seed=65)
+    yr.backward(dyh)
+    dxh, dWh, dbh = ops.head_bwd(xh, Wh, dyh)
+    rs += [_res("head.dx", dxh, xr.grad, 1e-5), _res("head.dW", dWh, Wr.grad, 1e-5), _res("head.db", dbh, br.grad, 1e-5)]
+    t = _rnd(5, 768, seed=66)
+    ty = ops.tanh_fwd(t)
+    rs += [_res("tanh", ty, torch.tanh(t), 1e-6), _res("tanh.bwd", ops.tanh_bwd(ty, t), t * (1 - torch.tanh(t) ** 2), 1e-5)]
+    return rs
+
+
+def check_embed_add():
+    rows, W = 500, 768
+    x = _rnd(rows, W, seed=67)
+    ids = torch.randint(0, 3, (rows,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    table = _rnd(3, W, seed=68)
+    rs = [_res("embed_add.fwd", ops.embed_add_fwd(x, ids, table), x + table[ids], 1e-6)]
+    dy = _rnd(rows, W, seed=69)
+    ref = torch.zeros(3, W, device=DEV).index_add_(0, ids, dy)
+    rs.append(_res("embed_add.bwd", ops.embed_add_bwd(dy, ids, 3), ref, 1e-5))
+    rs.append(_res("scatter_add_rows", ops.scatter_add_rows(dy, ids, 3), ref, 1e-5))
+    return rs
+
+
+def check_conv0_gn(dtype):
+    B, T_in, Cc, K, s = 2, 1605, 512, 10, 5
+    T_out = (T_in - K) // s + 1
+    wave = _rnd(B, T_in, scale=0.5, seed=70)
+    w = _rnd(Cc, 1, K, scale=0.3, seed=71)
+    gamma, beta = 1 + 0.1 * _rnd(Cc, seed=72), 0.1 * _rnd(Cc, seed=73)
+    y0 = ops.conv0_fwd(wave, w, None, T_out, s, dtype)
+    wr = w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    c_ref = F.conv1d(wave[:, None], wr, stride=s)            # [B, C, T_out]
+    tol = 1e-2 if dtype == torch.bfloat16 else 3e-5
+    rs = [_res(f"conv0.fwd[{dtype}]", y0, c_ref.permute(0, 2, 1), tol)]
+    y1, stats = ops.gn_gelu_fwd(y0, gamma, beta, 1e-5)
+    c_in = y0.float().permute(0, 2, 1).detach().requires_grad_(True)
+    g_ref = F.gelu(F.group_norm(c_in, Cc, gr, br, 1e-5))
+    rs.append(_res(f"gn_gelu.fwd[{dtype}]", y1, g_ref.permute(0, 2, 1), tol))
+    dy = _rnd(B, T_out, Cc, dtype=dtype, seed=74)
+    g_ref.backward(dy.float().permute(0, 2, 1))
+    dx, dg, db = ops.gn_gelu_bwd(y0, dy, gamma, beta, stats)
+    tolb = 3e-2 if dtype == torch.bfloat16 else 2e-4
+    rs += [_res(f"gn_gelu.dx[{dtype}]", dx, c_in.grad.permute(0, 2, 1), tolb), _res("gn_gelu.dgamma", dg, gr.grad, tolb),
+           _res("gn_gelu.dbeta", db, br.grad, tolb)]
+    c_ref.backward(dx.float().permute(0, 2, 1))
+    dw, _ = ops.conv0_bwd_w(wave, dx, K, s, False)
+    rs.append(_res(f"conv0.dw[{dtype}]", dw, wr.grad, 1e-4))
+    return rs
+
+
+def check_posconv(dtype):
+    """grouped conv k=128, pad 64, drop last, GELU, + residual: forward and all gradients vs torch."""
+    B, T, H, G, K = 2, 49, 256, 4, 128
+    Cg = H // G
+    x = _rnd(B, T, H, seed=80)                                   # f32 residual stream
+    v = _rnd(H, Cg, K, scale=0.05, seed=81)
+    g = (1.0 + 0.1 * _rnd(K, seed=82)).abs()
+    bias = 0.1 * _rnd(H, seed=83)
+    w, wf, norms = ops.weight_norm_fwd(v, g, dtype)
+    xg = ops.group_pad(x.view(B * T, H), B, T, H, G, 64, 64, dtype)
+    TP = T + 128
+    y, pre = ops.gemm_nt(xg, w, bias=bias, act=1, resid=x.view(B * T, H), want_pre=True, out_dtype=torch.float32,
+                         M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg, ldc=H, nzb=B, nzg=G, a_zb=G * TP * Cg, a_zg=TP * Cg,
+                         b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, bias_zg=Cg, out_shape=(B * T, H))
+    xr = x.clone().requires_grad_(True)
+    vr, gr_, br = v.clone().requires_grad_(True), g.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    wr = gr_[None, None, :] * vr / vr.pow(2).sum((0, 1), keepdim=True).sqrt()
+    conv = F.conv1d(xr.permute(0, 2, 1), wr, br, padding=64, groups=G)[:, :, :-1]
+    ref = xr + F.gelu(conv).permute(0, 2, 1)
+    tol = 2e-2 if dtype == torch.bfloat16 else 5e-5
+    rs = [_res(f"posconv.fwd[{dtype}]", y, ref.reshape(B * T, H), tol)]
+    gout = _rnd(B * T, H, seed=84)
+    ref.backward(gout.view(B, T, H))
+    du = ops.gelu_bwd(pre, gout)                                  # f32 [B*T, H]
+    dug = ops.group_pad(du, B, T, H, G, 63, 64, dtype)
+    dx = ops.gemm_nt(dug, wf, resid=gout, out_dtype=torch.float32, M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg, ldc=H, nzb=B, nzg=G,
+                     a_zb=G * TP * Cg, a_zg=TP * Cg, b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, out_shape=(B * T, H))
+    rs.append(_res(f"posconv.dx[{dtype}]", dx, xr.grad.reshape(B * T, H), tol))
+    du_lp = ops.cast2d(du, dtype)
+    dw = torch.empty(G, Cg, K * Cg, dtype=torch.float32, device=DEV)
+    for gi in range(G):
+        ops.gemm_tn(du_lp[:, gi * Cg:], xg[:, gi], out=dw[gi], N1=Cg, N2=K * Cg, lda=H, ldb=Cg, rows_per_batch=T, nbatch=B,
+                    a_zb=T * H, b_zb=G * TP * Cg)
+    dv, dg = ops.weight_norm_bwd(v, g, norms, dw)
+    tolw = 3e-2 if dtype == torch.bfloat16 else 2e-4
+    rs += [_res(f"posconv.dv[{dtype}]", dv, vr.grad, tolw), _res(f"posconv.dg[{dtype}]", dg, gr_.grad, tolw),
+           _res("posconv.dbias", ops.colsum(du), br.grad, 1e-4)]
+    return rs
+
+
+def all_checks():
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        out.append(lambda d=dtype: check_gemm_nt(d))
+        out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=768, K=768, act=1, pre=True, resid=False))
+        out.append(lambda d=dtype: check_gemm_nt(d, M=129, N=2304, K=768, resid=False))
+        out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
+        out.append(lambda d=dtype: check_gemm_tn(d))
+        out.append(lambda d=dtype: check_gemm_tn(d, M=249, N1=768, N2=512, nbatch=3))
+        out.append(lambda d=dtype: check_conv_as_gemm(d))
+        out.append(lambda d=dtype: check_conv_as_gemm(d, k=2, T_in=100))
+        for mode in (0, 1, 2):
+            out.append(lambda d=dtype, m=mode: check_attention(d, m))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=64, nh=1))
+        out.append(lambda d=dtype: check_attention(d, 2, B=1, S=481, nh=12))
+        out.append(lambda d=dtype: check_layernorm(d))
+        out.append(lambda d=dtype: check_layernorm(d, W=512, act=1))
+        out.append(lambda d=dtype: check_layernorm(d, W=1024))
+        out.append(lambda d=dtype: check_conv0_gn(d))
+        out.append(lambda d=dtype: check_posconv(d))
+    out.append(lambda: check_gemm_nt(torch.bfloat16, out_f32=True))
+    out += [check_cast_weight, check_colsum, check_text_embed, lambda: check_text_embed(-1), check_patchify,
+            check_pool_head_ce, check_embed_add]
+    return out

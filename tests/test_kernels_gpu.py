@@ -1,0 +1,18 @@
+"""-m gpu: every libtavhip kernel against a plain PyTorch reference of the same op (tests/kernel_checks.py)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    import kernel_checks
+    return kernel_checks.all_checks()
+
+
+@pytest.mark.parametrize("idx", range(64))
+def test_kernel_check(gpu, idx):
+    cases = _cases()
+    if idx >= len(cases):
+        pytest.skip("no such case")
+    for name, err, tol, ok in cases[idx]():
+        assert ok, f"{name}: rel err {err:.3e} > tol {tol:.1e}"
