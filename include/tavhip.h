@@ -104,6 +104,8 @@ typedef struct tav_attn_args {
     const float* key_mask;  /* [B][S] f32 or NULL */
     float* lse;             /* [B][nheads][S]     */
     float* corr;            /* [B][nheads][64], mask_mode 2 only */
+    void* o_soft;           /* mask_mode 2 only: softmax(s) v WITHOUT the rank-1 term, layout/dtype of o; the backward
+                               forms delta = dO . o_soft from it (o - corr would cancel catastrophically, |mask| ~ 6.5e4) */
     /* backward only */
     const void* dout; void* dq; void* dk; void* dv;
     float* delta;           /* workspace [B][nheads][S] f32 */
@@ -144,8 +146,11 @@ int tav_ln_bwd_partials(int64_t rows);
 /* ---------------------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels (all HBM-bound). */
 
-/* dst = cast(src) ; optionally also dst_t[c][r] = cast(src[r][c]) (the W^T copy used by dgrad). src f32 [R][C]. */
-int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
+/* dst[r][c] = cast(src[r][c]) (row stride ld_dst, 0 = C) and/or dst_t[c][r] = cast(src[r][c]) (row stride ld_dst_t,
+ * 0 = R): the per-step operand copies of an f32 parameter [R][C]; the transposed copy is the dgrad operand.  Strides let
+ * q/k/v weights land in one fused [3H][K] / [K][3H] operand. */
+int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int32_t dst_dtype,
+                    void* stream);
 /* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst) and its dgrad form [k*ci... see DESIGN.md] */
 int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
 /* generic strided cast/copy: dst[r][c] = src[r][c] for r<R, c<C (dtypes may differ) */

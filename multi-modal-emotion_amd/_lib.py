@@ -35,7 +35,7 @@ class GemmTNArgs(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("key_mask", vp), ("lse", vp), ("corr", vp),
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("key_mask", vp), ("lse", vp), ("corr", vp), ("o_soft", vp),
                 ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp),
                 ("B", i64), ("S", i64), ("nheads", i64),
                 ("ld_q", i64), ("ld_k", i64), ("ld_v", i64), ("ld_o", i64), ("ld_do", i64), ("ld_dq", i64), ("ld_dk", i64), ("ld_dv", i64),
@@ -68,7 +68,7 @@ _SIGS = {
     "tav_ln_fwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd_partials": (C.c_int, [i64]),
-    "tav_cast_weight": (C.c_int, [vp, i64, i64, vp, vp, i32, vp]),
+    "tav_cast_weight": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i32, vp]),
     "tav_cast_conv_weight": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp]),
     "tav_cast2d": (C.c_int, [vp, i32, i64, vp, i32, i64, i64, i64, vp]),
     "tav_add_f32": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),

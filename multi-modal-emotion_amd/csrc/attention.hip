@@ -22,7 +22,7 @@
 namespace tav {
 
 struct AttnP {
-    const char* q; const char* k; const char* v; char* o;
+    const char* q; const char* k; const char* v; char* o; char* o_soft;
     const float* mask; float* lse; float* corr;
     const char* dout; char* dq; char* dk; char* dv; float* delta;
     int B, S, nh;
@@ -235,10 +235,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
         if (q < S) {
             const float inv = 1.f / l;
             T* orow = reinterpret_cast<T*>(p.o) + ((long)b * S + q) * p.ld_o + head * 64;
+            T* srow = reinterpret_cast<T*>(p.o_soft) + ((long)b * S + q) * p.ld_o + head * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 v = oacc[dt][qt] * inv;
-                if (MODE == 2) v += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g);
+                if (MODE == 2) {   // keep softmax(s)·v on its own: o - c cancels catastrophically once |mask| ~ 6.5e4
+                    st4(srow + 16 * dt + 4 * g, v);
+                    v += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g);
+                }
                 st4(orow + 16 * dt + 4 * g, v);
             }
             if (g == 0) p.lse[((long)b * p.nh + head) * S + q] = m_run[qt] + __logf(l);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 }
 
 // ================================================================================================= backward: delta
-// delta[b][h][q] = sum_d dO[q][d] * (O[q][d] - corr[d])
+// delta[b][h][q] = sum_d dO[q][d] * (softmax(s) v)[q][d]   (mode 2 reads the o_soft copy, never o - corr)
 template <typename T, int MODE>
 __global__ void attn_bwd_delta_kernel(const AttnP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -257,11 +261,10 @@ __global__ void attn_bwd_delta_kernel(const AttnP p) {
     const int head = (int)(row % p.nh);
     const long bs = row / p.nh;
     const int b = (int)(bs / p.S), s = (int)(bs - (long)b * p.S);
-    const float o = ET<T>::ld(reinterpret_cast<const T*>(p.o) + bs * p.ld_o + head * 64 + lane);
+    const T* osrc = reinterpret_cast<const T*>(MODE == 2 ? p.o_soft : p.o);
+    const float o = ET<T>::ld(osrc + bs * p.ld_o + head * 64 + lane);
     const float d_o = ET<T>::ld(reinterpret_cast<const T*>(p.dout) + bs * p.ld_do + head * 64 + lane);
-    float c = 0.f;
-    if (MODE == 2) c = p.corr[((long)b * p.nh + head) * 64 + lane];
-    const float v = wave_sum(d_o * (o - c));
+    const float v = wave_sum(d_o * o);
     if (lane == 0) p.delta[((long)b * p.nh + head) * p.S + s] = v;
 }
 
@@ -564,7 +567,7 @@ static int check(const tav_attn_args* a, bool bwd) {
     if (a->dtype != TAV_BF16 && a->dtype != TAV_F32) return TAV_ERR_DTYPE;
     if (a->mask_mode < 0 || a->mask_mode > 2) return TAV_ERR_SHAPE;
     if (a->mask_mode != 0 && !a->key_mask) return TAV_ERR_NULL;
-    if (a->mask_mode == 2 && !a->corr) return TAV_ERR_NULL;
+    if (a->mask_mode == 2 && (!a->corr || !a->o_soft)) return TAV_ERR_NULL;
     const int pk = a->dtype == TAV_BF16 ? 8 : 4;
     if (a->ld_q % pk || a->ld_k % pk || a->ld_v % pk || a->ld_o % 4) return TAV_ERR_ALIGN;
     if (a->ld_q < a->nheads * 64 || a->ld_k < a->nheads * 64 || a->ld_v < a->nheads * 64 || a->ld_o < a->nheads * 64) return TAV_ERR_SHAPE;
@@ -576,7 +579,7 @@ static int check(const tav_attn_args* a, bool bwd) {
 }
 static AttnP pack(const tav_attn_args* a) {
     AttnP p;
-    p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->o;
+    p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->o; p.o_soft = (char*)a->o_soft;
     p.mask = a->key_mask; p.lse = a->lse; p.corr = a->corr;
     p.dout = (const char*)a->dout; p.dq = (char*)a->dq; p.dk = (char*)a->dk; p.dv = (char*)a->dv; p.delta = a->delta;
     p.B = (int)a->B; p.S = (int)a->S; p.nh = (int)a->nheads;

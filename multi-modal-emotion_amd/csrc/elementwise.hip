@@ -8,21 +8,21 @@ namespace tav {
 
 // ------------------------------------------------------------------------------------------------ weight casts
 template <typename TD>
-__global__ void cast_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, TD* __restrict__ dst_t, int R, int C) {
+__global__ void cast_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, long ld_n, TD* __restrict__ dst_t, long ld_t, int R, int C) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, c = c0 + tx;
         float v = 0.f;
-        if (r < R && c < C) { v = src[(long)r * C + c]; if (dst) ET<TD>::st(dst + (long)r * C + c, v); }
+        if (r < R && c < C) { v = src[(long)r * C + c]; if (dst) ET<TD>::st(dst + (long)r * ld_n + c, v); }
         tile[k][tx] = v;
     }
     __syncthreads();
     if (dst_t) {
         for (int k = ty; k < 32; k += 8) {
             const int c = c0 + k, r = r0 + tx;
-            if (r < R && c < C) ET<TD>::st(dst_t + (long)c * R + r, tile[tx][k]);
+            if (r < R && c < C) ET<TD>::st(dst_t + (long)c * ld_t + r, tile[tx][k]);
         }
     }
 }
@@ -363,12 +363,13 @@ extern "C" const char* tav_error_string(int code) {
     }
 }
 
-extern "C" int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, void* dst_t, int32_t dt, void* stream) {
+extern "C" int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int32_t dt, void* stream) {
     if (!src || (!dst && !dst_t)) return TAV_ERR_NULL;
     if (R <= 0 || C <= 0) return TAV_ERR_SHAPE;
+    const long ld_n = ld_dst > 0 ? ld_dst : C, ld_t = ld_dst_t > 0 ? ld_dst_t : R;
     dim3 grid(tav_cdiv(C, 32), tav_cdiv(R, 32));
-    if (dt == TAV_BF16) hipLaunchKernelGGL((cast_weight_kernel<bf16>), grid, dim3(256), 0, ST, src, (bf16*)dst, (bf16*)dst_t, (int)R, (int)C);
-    else if (dt == TAV_F32) hipLaunchKernelGGL((cast_weight_kernel<float>), grid, dim3(256), 0, ST, src, (float*)dst, (float*)dst_t, (int)R, (int)C);
+    if (dt == TAV_BF16) hipLaunchKernelGGL((cast_weight_kernel<bf16>), grid, dim3(256), 0, ST, src, (bf16*)dst, ld_n, (bf16*)dst_t, ld_t, (int)R, (int)C);
+    else if (dt == TAV_F32) hipLaunchKernelGGL((cast_weight_kernel<float>), grid, dim3(256), 0, ST, src, (float*)dst, ld_n, (float*)dst_t, ld_t, (int)R, (int)C);
     else return TAV_ERR_DTYPE;
     return tav_last_error();
 }

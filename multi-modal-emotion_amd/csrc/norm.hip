@@ -114,18 +114,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
     }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= W) return;
+// one workgroup per 64 columns: 4 row-groups x 64 columns, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W,
+                                                              int accumulate) {
+    __shared__ float red[4][64][2];
+    const int l = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
     float g = 0.f, b = 0.f;
-    for (int k = 0; k < nblocks; ++k) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+    if (c < W)
+        for (int k = rg; k < nblocks; k += 4) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
+    red[rg][l][0] = g; red[rg][l][1] = b;
+    __syncthreads();
+    if (rg == 0 && c < W) {
+        g = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
+        b = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+    }
 }
 
 static inline int ln_blocks(long rows) {
-    long b = (rows + 3) / 4;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    long b = (rows + 15) / 16;      // >= 4 rows per wave so the per-lane dgamma/dbeta partials amortise
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 // ------------------------------------------------------------------------------------------------ group norm over time
@@ -288,7 +297,7 @@ extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
     int e = (int)hipGetLastError();
     if (e) return e;
     if (p.partials) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 256)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 64)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
                            a->accumulate_params);
         e = (int)hipGetLastError();
     }

@@ -96,10 +96,10 @@ def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale):
+def _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft=None):
     a = L.AttnArgs()
     a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(o)
-    a.key_mask, a.lse, a.corr = ptr(key_mask), ptr(lse), ptr(corr)
+    a.key_mask, a.lse, a.corr, a.o_soft = ptr(key_mask), ptr(lse), ptr(corr), ptr(o_soft)
     a.B, a.S, a.nheads = B, S, nheads
     a.ld_q, a.ld_k, a.ld_v, a.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
     a.dtype, a.mask_mode, a.scale = dt(q), mask_mode, scale
@@ -112,9 +112,10 @@ def attn_fwd(q, k, v, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125):
     o = torch.empty(B * S, H, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, nheads, S, dtype=torch.float32, device=q.device)
     corr = torch.empty(B, nheads, 64, dtype=torch.float32, device=q.device) if mask_mode == 2 else None
-    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale)
+    o_soft = torch.empty_like(o) if mask_mode == 2 else None
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft)
     check(lib().tav_attn_fwd(C.byref(a), stream()), "attn_fwd")
-    return o, lse, corr
+    return o, lse, (corr, o_soft)
 
 
 def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, dqkv=None):
@@ -124,7 +125,8 @@ def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_m
         dqkv = torch.empty(B * S, 3 * H, dtype=q.dtype, device=q.device)
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     delta = workspace("attn_delta", B * nheads * S, q.device)
-    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale)
+    corr, o_soft = corr if corr is not None else (None, None)
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft)
     a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
     a.ld_do, a.ld_dq, a.ld_dk, a.ld_dv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
     check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd")
@@ -170,12 +172,14 @@ def ln_bwd(dy, x, gamma, beta, mean, rstd, *, dx_add=None, want_f32=True, lp_dty
 
 
 # ---------------------------------------------------------------------------------------------- casts & small ops
-def cast_weight(w, dtype, *, want_t=True, want_n=True):
-    """f32 [R,C] parameter -> (copy in dtype [R,C], transposed copy [C,R])."""
+def cast_weight(w, dtype, *, want_t=True, want_n=True, out_n=None, out_t=None):
+    """f32 [R,C] parameter -> (copy in dtype [R,C], transposed copy [C,R]).  out_n / out_t may be (strided) views of a
+    larger fused operand (row stride taken from the view)."""
     R, Cc = w.shape
-    n = torch.empty(R, Cc, dtype=dtype, device=w.device) if want_n else None
-    t = torch.empty(Cc, R, dtype=dtype, device=w.device) if want_t else None
-    check(lib().tav_cast_weight(ptr(w), R, Cc, ptr(n), ptr(t), dt(dtype), stream()), "cast_weight")
+    n = out_n if out_n is not None else (torch.empty(R, Cc, dtype=dtype, device=w.device) if want_n else None)
+    t = out_t if out_t is not None else (torch.empty(Cc, R, dtype=dtype, device=w.device) if want_t else None)
+    check(lib().tav_cast_weight(ptr(w), R, Cc, ptr(n), n.stride(0) if n is not None else 0, ptr(t), t.stride(0) if t is not None else 0,
+                                dt(dtype), stream()), "cast_weight")
     return n, t
 
 

@@ -1,0 +1,255 @@
+"""Pin the oracle (build container only; never runs on the GPU box).
+
+1. Imports the reference's own fusion code (/root/reference/utils/TAVFormer.py: VideoMAEEncoder, TransformerEncoder) and
+   the Hugging Face classes the reference calls (RobertaModel/BertModel, Wav2Vec2Model, VideoMAEModel) instantiated from
+   LOCAL config objects (no from_pretrained: the container is offline), fills them with closed-form weights
+   (tests/closed_form.py) and checks oracle/tav_oracle.py against them on closed-form inputs.
+2. Composes those modules exactly as models/tav.py:344-417 and :473-504 read (models/tav.py itself cannot be imported:
+   it needs pytorchvideo/torchvision/torchaudio and fetches a processor at import time) and writes the
+   expected outputs to tests/golden/*.npz.  Fixtures hold outputs only; weights and inputs are closed-form.
+
+Usage:  python oracle/validate_vs_reference.py [--write]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), "/root/reference"]
+
+import closed_form as cf  # noqa: E402
+from oracle import tav_oracle as O  # noqa: E402
+
+torch.manual_seed(0)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def hf_text(cfg):
+    from transformers import BertConfig, BertModel, RobertaConfig, RobertaModel
+    kw = dict(num_hidden_layers=cfg["layers"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"], intermediate_size=cfg["inter"],
+              vocab_size=cfg["vocab"], max_position_embeddings=cfg["max_pos"], type_vocab_size=cfg["type_vocab"], layer_norm_eps=cfg["eps"],
+              pad_token_id=cfg["pad_id"], attn_implementation="eager")
+    m = RobertaModel(RobertaConfig(**kw)) if cfg["kind"] == "roberta" else BertModel(BertConfig(**kw))
+    return cf.fill_module_(m).eval()
+
+
+def hf_audio(cfg):
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    c = Wav2Vec2Config(num_hidden_layers=cfg["layers"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"], intermediate_size=cfg["inter"],
+                       feat_extract_norm=cfg["feat_norm"], do_stable_layer_norm=cfg["stable_ln"], conv_bias=cfg["conv_bias"],
+                       conv_dim=cfg["conv_dim"], conv_kernel=cfg["conv_kernel"], conv_stride=cfg["conv_stride"],
+                       num_conv_pos_embeddings=cfg["pos_k"], num_conv_pos_embedding_groups=cfg["pos_groups"], layer_norm_eps=cfg["eps"],
+                       attn_implementation="eager")
+    return cf.fill_module_(Wav2Vec2Model(c)).eval()
+
+
+def hf_video(cfg):
+    from transformers import VideoMAEConfig, VideoMAEModel
+    c = VideoMAEConfig(num_hidden_layers=cfg["layers"], hidden_size=cfg["hidden"], num_attention_heads=cfg["heads"], intermediate_size=cfg["inter"],
+                       image_size=cfg["image"], patch_size=cfg["patch"], num_frames=cfg["frames"], tubelet_size=cfg["tubelet"],
+                       layer_norm_eps=cfg["eps"], attn_implementation="eager")
+    return cf.fill_module_(VideoMAEModel(c)).eval(), c
+
+
+class RefPreFormer(torch.nn.Module):
+    """models/tav.py:254-267 built from local configs (same attribute names => same state_dict keys)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.bert = hf_text(cfg["text"])
+        self.wav2vec2 = hf_audio(cfg["audio"])
+        self.masked_spec_embed = torch.nn.Parameter(torch.zeros(cfg["audio"]["hidden"]))
+        self.videomae, _ = hf_video(cfg["video"])
+        self.wav_2_768 = torch.nn.Linear(cfg["audio"]["hidden"], 768)
+        cf.fill_module_(self)
+
+    def forward(self, input_ids, audio_features, video_embeds, text_mask, audio_mask, visual_mask):
+        # text of models/tav.py:344-417 with train=False, device="cpu"
+        embedded_bert = self.bert.embeddings(input_ids=input_ids)
+        extract_features = self.wav2vec2.feature_extractor(audio_features)
+        audio_mask = self.wav2vec2._get_feature_vector_attention_mask(extract_features.shape[2], audio_mask, add_adapter=False)
+        embedded_audio, _ = self.wav2vec2.feature_projection(extract_features.transpose(1, 2))
+        embedded_audio = embedded_audio + self.wav2vec2.encoder.pos_conv_embed(embedded_audio)
+        embedded_audio = self.wav2vec2.encoder.layer_norm(embedded_audio)
+        embedded_audio = self.wav_2_768(embedded_audio)
+        embedded_video = self.videomae.embeddings(video_embeds, ~visual_mask)
+        tav = torch.concat((embedded_bert, embedded_audio, embedded_video), dim=1)
+        B, St, _ = embedded_bert.shape
+        text_pos = torch.zeros((B, St))
+        text_mask = (1.0 - text_mask[:, None, None, :]) * torch.finfo(torch.float16).min
+        audio_pos = torch.ones((B, embedded_audio.shape[1]))
+        audio_mask = 1.0 - audio_mask[:, None, None, :] * torch.finfo(torch.float16).min
+        visual_pos = torch.ones((B, embedded_video.shape[1])) + 1
+        vmask = torch.zeros((B, 1, 1, embedded_video.shape[1])).type(torch.float)
+        tav_embed = torch.concat((text_pos, audio_pos, visual_pos), dim=1).type(torch.LongTensor)
+        return tav, tav_embed, torch.concat((text_mask, audio_mask, vmask), dim=-1)
+
+
+class RefTAVForMAE(torch.nn.Module):
+    """models/tav.py:425-458 from local configs; random_mae_encoder is the REFERENCE's utils/TAVFormer.VideoMAEEncoder."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        from utils.TAVFormer import VideoMAEEncoder   # /root/reference
+        self.embedding = torch.nn.Embedding(3, 768)
+        self.bert = hf_text(cfg["text"])
+        self.bert_norm = torch.nn.LayerNorm(768)
+        _, vcfg = hf_video(dict(cfg["video"], layers=1))
+        self.random_mae_encoder = VideoMAEEncoder(vcfg, cfg["fusion"]["layers"])
+        self.rand_norm = torch.nn.LayerNorm(768)
+        self.vid_norm = torch.nn.LayerNorm(768)
+        self.aud_norm = torch.nn.LayerNorm(768)
+        self.linear1 = torch.nn.Linear(768 * 4, cfg["output_dim"])
+        self.wav2vec2 = hf_audio(cfg["audio"])
+        self.videomae, _ = hf_video(cfg["video"])
+        self.wav_2_768_2 = torch.nn.Linear(cfg["audio"]["hidden"], 768)
+        cf.fill_module_(self)
+        self.eval()
+
+    def forward(self, input_ids, text_attention_mask, audio_features, video_embeds, visual_mask, hidden_states, pos_embed, attention_mask):
+        av = hidden_states + self.embedding(pos_embed)
+        aud_outputs = self.wav2vec2(audio_features)[0]
+        aud_outputs = torch.mean(self.wav_2_768_2(aud_outputs), dim=1)
+        vid_outputs = self.videomae(video_embeds, visual_mask)[0]
+        vid_outputs = torch.mean(vid_outputs, dim=1)
+        out = self.bert(input_ids=input_ids, attention_mask=text_attention_mask, return_dict=False)
+        t = self.bert_norm(out[1])
+        av = self.random_mae_encoder(av, attention_mask)
+        av = self.rand_norm(torch.mean(av, dim=1))
+        aud_outputs = self.aud_norm(aud_outputs)
+        vid_outputs = self.vid_norm(vid_outputs)
+        tav = torch.cat([av, t, aud_outputs, vid_outputs], dim=1)
+        return self.linear1(tav)
+
+
+def tiny_cfg(name):
+    cfg = O.preset(name + "-tiny")
+    cfg["video"] = dict(cfg["video"], image=32)        # 2x2x8 = 32 tubelet tokens: true widths, CPU-sized
+    return cfg
+
+
+def grad_norm(params):
+    return torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    worst = 0.0
+    out = {}
+
+    # ---- 1. fusion encoder: reference class vs oracle ------------------------------------------------------------
+    from transformers import VideoMAEConfig
+    from utils.TAVFormer import TransformerEncoder, VideoMAEEncoder
+    enc = cf.fill_module_(VideoMAEEncoder(VideoMAEConfig(), 2))
+    sd = {"f." + k: v for k, v in enc.state_dict().items()}
+    fcfg = dict(layers=2, heads=12, eps=1e-12)
+    for S in (8, 37):
+        x = cf.tensor_for(f"fusion_x{S}", (2, S, 768), kind="bias") * 20
+        masks = {"none": None, "zeros": torch.zeros(2, 1, 1, S)}
+        m = torch.zeros(2, 1, 1, S)
+        m[..., : S // 4] = O.FP16_MIN
+        m[..., S // 4: S // 2] = 65505.0
+        m[0, ..., S // 2 - 1] = 1.0
+        masks["refstyle"] = m
+        for mname, mask in masks.items():
+            xr = x.clone().requires_grad_(True)
+            enc.zero_grad()
+            y_ref = enc(xr, mask)
+            y_ref.square().mean().backward()
+            xo = x.clone().requires_grad_(True)
+            sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            y_or = O.fusion_encoder(sdo, "f", xo, mask, fcfg)
+            y_or.square().mean().backward()
+            e = max(rel(y_or, y_ref), rel(xo.grad, xr.grad), rel(sdo["f.layer.0.intermediate.dense.weight"].grad, enc.layer[0].intermediate.dense.weight.grad))
+            worst = max(worst, e)
+            print(f"fusion S={S} mask={mname}: rel err {e:.2e}  |y|max {y_ref.abs().max():.3e}")
+            out[f"fusion_S{S}_{mname}_y"] = y_ref.detach().numpy()
+            out[f"fusion_S{S}_{mname}_dx"] = xr.grad.numpy()
+            out[f"fusion_S{S}_{mname}_dW1_l0"] = enc.layer[0].intermediate.dense.weight.grad.numpy()[:8, :8].copy()
+    for early in (False, True):
+        te = cf.fill_module_(TransformerEncoder(768, num_layers=1, early_div=early)).eval()
+        x = cf.tensor_for("te_x", (2, 11, 768), kind="bias") * 20
+        m = torch.zeros(2, 1, 1, 11)
+        m[..., 8:] = O.FP16_MIN
+        y_ref = te(x.clone(), m)
+        y_or = O.transformer_encoder({"t." + k: v for k, v in te.state_dict().items()}, "t", x, m, 1, 12, early)
+        e = rel(y_or, y_ref)
+        worst = max(worst, e)
+        print(f"TransformerEncoder early_div={early}: rel err {e:.2e}")
+        out[f"transformer_encoder_early{int(early)}_y"] = y_ref.detach().numpy()
+
+    # ---- 2. HF encoders vs oracle, 3. composed PreFormer / TAVForMAE, per preset ------------------------------------
+    for name in ("A", "B"):
+        cfg = tiny_cfg(name)
+        batch, labels = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=16, image=32, vocab=cfg["text"]["vocab"], pad_id=cfg["text"]["pad_id"], nkeep_fusion=4)
+        pre, model = RefPreFormer(cfg), RefTAVForMAE(cfg)
+        sd_pre = {k: v for k, v in pre.state_dict().items()}
+        sd_model = {k: v for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            seq, pooled = model.bert(input_ids=batch["input_ids"], attention_mask=batch["text_mask"], return_dict=False)[:2]
+            o_seq, o_pool = O.text_encoder(sd_model, "bert", cfg["text"], batch["input_ids"], batch["text_mask"])
+            aud = model.wav2vec2(batch["audio_features"])[0]
+            o_aud = O.w2v2_model(sd_model, "wav2vec2", cfg["audio"], batch["audio_features"])
+            vid = model.videomae(batch["video_embeds"], batch["visual_mask"])[0]
+            o_vid = O.videomae_model(sd_model, "videomae", cfg["video"], batch["video_embeds"], batch["visual_mask"])
+        for nm, a, b in (("text.seq", o_seq, seq), ("text.pooled", o_pool, pooled), ("audio", o_aud, aud), ("video", o_vid, vid)):
+            e = rel(a, b)
+            worst = max(worst, e)
+            print(f"preset {name} HF {nm}: rel err {e:.2e} shape {tuple(b.shape)}")
+        out[f"{name}_text_pooled"] = pooled.numpy()
+        out[f"{name}_audio_last"] = aud.numpy()
+        out[f"{name}_video_mean"] = vid.mean(1).numpy()
+
+        params = [p for p in list(pre.parameters()) + list(model.parameters()) if p.requires_grad]
+        tav, tav_embed, amask = pre(batch["input_ids"], batch["audio_features"], batch["video_embeds"], batch["text_mask"], batch["audio_mask"], batch["visual_mask"])
+        logits = model(batch["input_ids"], batch["text_mask"], batch["audio_features"], batch["video_embeds"], batch["visual_mask"], tav, tav_embed, amask)
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        gn = grad_norm(params)
+
+        sdp = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_pre.items()}
+        sdm = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_model.items()}
+        o_tav, o_embed, o_mask = O.preformer_forward(sdp, cfg, batch["input_ids"], batch["audio_features"], batch["video_embeds"], batch["text_mask"],
+                                                     batch["audio_mask"], batch["visual_mask"])
+        o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, labels)
+        o_loss.backward()
+        o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in list(sdp.values()) + list(sdm.values()) if v.requires_grad and v.grad is not None)).item()
+        errs = dict(tav=rel(o_tav, tav), mask=rel(o_mask, amask), embed=float((o_embed != tav_embed).any()), logits=rel(o_logits, logits),
+                    loss=abs(o_loss.item() - loss.item()) / abs(loss.item()), gradnorm=abs(o_gn - gn) / gn)
+        worst = max(worst, *errs.values())
+        print(f"preset {name} composed: " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()) + f"   loss {loss.item():.6f} gradnorm {gn:.4e}")
+        print(f"   logits {logits.detach().numpy()[0]}")
+        out[f"{name}_pre_tav"] = tav.detach().numpy()
+        out[f"{name}_pre_tav_embed"] = tav_embed.numpy()
+        out[f"{name}_pre_attention_mask"] = amask.numpy()
+        out[f"{name}_logits"] = logits.detach().numpy()
+        out[f"{name}_loss"] = np.array([loss.item()])
+        out[f"{name}_gradnorm"] = np.array([gn])
+        g = dict(model.named_parameters())
+        out[f"{name}_grad_linear1"] = g["linear1.weight"].grad.numpy()[:, :16].copy()
+        out[f"{name}_grad_fusion_q0"] = g["random_mae_encoder.layer.0.attention.attention.query.weight"].grad.numpy()[:8, :8].copy()
+        gp = dict(pre.named_parameters())
+        out[f"{name}_grad_pre_conv1"] = gp["wav2vec2.feature_extractor.conv_layers.1.conv.weight"].grad.numpy()[:4, :4].copy()
+
+    print(f"worst relative difference oracle vs reference-side modules: {worst:.2e}")
+    if worst > 2e-4:
+        print("ORACLE NOT PINNED")
+        sys.exit(1)
+    if args.write:
+        path = os.path.join(GOLD, "tav_golden.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -96,7 +96,7 @@ def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
     rs.append(_res(f"conv_gemm.dx[{dtype}]", dx, xr.grad.permute(0, 2, 1), tol))
     dw = ops.gemm_tn(du, x, N1=Cc, N2=k * Cc, lda=Cc, ldb=s * Cc, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Cc,
                      b_zb=T_in * Cc, perm_inner=Cc, perm_outer=k, out_shape=(Cc, Cc, k))
-    rs.append(_res(f"conv_gemm.dw[{dtype}]", dw, wr.grad, 3e-3 if dtype == torch.bfloat16 else 2e-5))
+    rs.append(_res(f"conv_gemm.dw[{dtype}]", dw, wr.grad, 1e-2 if dtype == torch.bfloat16 else 2e-5))
     return rs
 
 
@@ -111,7 +111,9 @@ def _attn_ref(q, k, v, mask, mode, scale):
     return torch.einsum("bhqk,bhkd->bhqd", p, v)
 
 
-def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True):
+def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True, ref_style_mask=False):
+    """ref_style_mask: the values PreFormer really produces (models/tav.py:383-397): {0,-65504} text, {65505,1} audio,
+    {0} video.  The rank-1 term then dwarfs softmax(s)v, so the check is against an fp64 reference."""
     H = nh * 64
     qkv = _rnd(B * S, 3 * H, dtype=dtype, seed=20 + mode)
     mask = None
@@ -123,25 +125,32 @@ def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True):
         mask[:, : S // 3] = -0.5
         mask[:, S // 3: S // 2] = 2.0
         mask[0, S // 2:] = 1.0
+        if ref_style_mask:
+            mask = torch.zeros(B, S, device=DEV)
+            mask[:, S // 4 - 9: S // 4] = -65504.0          # padded text tokens
+            mask[:, S // 4: S // 4 + S // 2] = 65505.0      # valid audio frames
+            mask[0, S // 4 + S // 2 - 20: S // 4 + S // 2] = 1.0   # padded audio frames of row 0
     q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
     o, lse, corr = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode)
 
+    rdt = torch.float64 if ref_style_mask else torch.float32
+
     def heads(t):
-        return t.float().reshape(B, S, nh, 64).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+        return t.to(rdt).reshape(B, S, nh, 64).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
 
     qr, kr, vr = heads(q), heads(k), heads(v)
-    o_ref = _attn_ref(qr, kr, vr, mask, mode, 0.125)
+    o_ref = _attn_ref(qr, kr, vr, mask.to(rdt) if mask is not None else None, mode, 0.125)
     tol = 2e-2 if dtype == torch.bfloat16 else 5e-5
-    rs = [_res(f"attn.fwd[{dtype},mode{mode},S{S}]", o, o_ref.permute(0, 2, 1, 3).reshape(B * S, H), tol)]
+    rs = [_res(f"attn.fwd[{dtype},mode{mode},S{S},ref{int(ref_style_mask)}]", o, o_ref.permute(0, 2, 1, 3).reshape(B * S, H), tol)]
     if bwd:
         do = _rnd(B * S, H, dtype=dtype, seed=30 + mode)
-        o_ref.backward(do.float().reshape(B, S, nh, 64).permute(0, 2, 1, 3))
+        o_ref.backward(do.to(rdt).reshape(B, S, nh, 64).permute(0, 2, 1, 3))
         dqkv = ops.attn_bwd(q, k, v, o, do, lse, corr, B, S, nh, key_mask=mask, mask_mode=mode)
 
         def flat(t):
             return t.permute(0, 2, 1, 3).reshape(B * S, H)
 
-        tolb = 3e-2 if dtype == torch.bfloat16 else 1e-4
+        tolb = (6e-2 if mode == 2 else 3e-2) if dtype == torch.bfloat16 else 1e-4
         rs.append(_res(f"attn.dq[{dtype},mode{mode}]", dqkv[:, :H], flat(qr.grad), tolb))
         rs.append(_res(f"attn.dk[{dtype},mode{mode}]", dqkv[:, H:2 * H], flat(kr.grad), tolb))
         rs.append(_res(f"attn.dv[{dtype},mode{mode}]", dqkv[:, 2 * H:], flat(vr.grad), tolb))
@@ -314,8 +323,9 @@ def check_posconv(dtype):
     ref.backward(gout.view(B, T, H))
     du = ops.gelu_bwd(pre, gout)                                  # f32 [B*T, H]
     dug = ops.group_pad(du, B, T, H, G, 63, 64, dtype)
+    TPd = T + 127
     dx = ops.gemm_nt(dug, wf, resid=gout, out_dtype=torch.float32, M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg, ldc=H, nzb=B, nzg=G,
-                     a_zb=G * TP * Cg, a_zg=TP * Cg, b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, out_shape=(B * T, H))
+                     a_zb=G * TPd * Cg, a_zg=TPd * Cg, b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, out_shape=(B * T, H))
     rs.append(_res(f"posconv.dx[{dtype}]", dx, xr.grad.reshape(B * T, H), tol))
     du_lp = ops.cast2d(du, dtype)
     dw = torch.empty(G, Cg, K * Cg, dtype=torch.float32, device=DEV)
@@ -325,7 +335,7 @@ def check_posconv(dtype):
     dv, dg = ops.weight_norm_bwd(v, g, norms, dw)
     tolw = 3e-2 if dtype == torch.bfloat16 else 2e-4
     rs += [_res(f"posconv.dv[{dtype}]", dv, vr.grad, tolw), _res(f"posconv.dg[{dtype}]", dg, gr_.grad, tolw),
-           _res("posconv.dbias", ops.colsum(du), br.grad, 1e-4)]
+           _res(f"posconv.dbias[{dtype}]", ops.colsum(du), br.grad, tolw)]
     return rs
 
 
@@ -344,6 +354,7 @@ def all_checks():
             out.append(lambda d=dtype, m=mode: check_attention(d, m))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=64, nh=1))
         out.append(lambda d=dtype: check_attention(d, 2, B=1, S=481, nh=12))
+        out.append(lambda d=dtype: check_attention(d, 2, B=2, S=481, nh=12, ref_style_mask=True))
         out.append(lambda d=dtype: check_layernorm(d))
         out.append(lambda d=dtype: check_layernorm(d, W=512, act=1))
         out.append(lambda d=dtype: check_layernorm(d, W=1024))
