@@ -1,0 +1,598 @@
+"""Execution engine of the TAV path: precision policy, per-step weight-operand cache and the autograd Functions that
+sequence libtavhip kernels for one transformer layer / front-end / tail.
+
+Design (MI355X-first):
+  * residual streams, LayerNorm/softmax statistics and every parameter gradient are f32; GEMM/attention operands are
+    bf16 (Policy("bf16")) or f32 (Policy("fp32"), exact-f32 MFMA, used for the 1e-3 parity runs);
+  * activations stay token-major [tokens, features]; q/k/v are column slices of one fused [tokens, 3H] buffer, so the
+    attention kernels and the QKV projection's backward share buffers without any head-split copies;
+  * each layer is ONE autograd node that launches ~12 kernels forward / ~20 backward on the current HIP stream and saves
+    exactly the tensors its backward needs; nothing is allocated or synchronised inside the kernels, so a whole step can
+    be captured into a hipGraph.
+"""
+import torch
+
+from . import ops
+
+_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Call after parameters were updated through raw pointers (our fused AdamW) so cached operand copies refresh."""
+    _EPOCH[0] += 1
+
+
+class Policy:
+    def __init__(self, name="bf16"):
+        name = {"bfloat16": "bf16", "float32": "fp32", "f32": "fp32"}.get(name, name)
+        if name not in ("bf16", "fp32"):
+            raise ValueError(f"unknown precision policy {name!r}")
+        self.name = name
+        self.lp = torch.bfloat16 if name == "bf16" else torch.float32
+        self.f32 = name == "fp32"
+
+
+class WeightCache:
+    """Low-precision (and transposed) operand copies of f32 parameters, rebuilt only when a parameter changed."""
+
+    def __init__(self, policy):
+        self.pol = policy
+        self.d = {}
+
+    def _get(self, key, params, build):
+        ver = (_EPOCH[0],) + tuple(p._version for p in params if p is not None)
+        e = self.d.get(key)
+        if e is not None and e[0] == ver:
+            return e[1]
+        with torch.no_grad():
+            val = build()
+        self.d[key] = (ver, val)
+        return val
+
+    def linear(self, w):
+        """-> (W [N,K], W^T [K,N]) in the operand dtype."""
+        def build():
+            if self.pol.f32:
+                return w.detach(), ops.cast_weight(w.detach(), torch.float32, want_n=False)[1]
+            return ops.cast_weight(w.detach(), self.pol.lp)
+        return self._get(("lin", id(w)), (w,), build)
+
+    def qkv(self, wq, wk, wv, bq, bk, bv):
+        """-> (Wqkv [3H,K], Wqkv^T [K,3H], bias [3H] f32) fused operands (biases that are None read as zero)."""
+        def build():
+            H, K = wq.shape
+            dev = wq.device
+            n = torch.empty(3 * H, K, dtype=self.pol.lp, device=dev)
+            t = torch.empty(K, 3 * H, dtype=self.pol.lp, device=dev)
+            bias = ops.zeros_f32((3 * H,), dev)
+            for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                ops.cast_weight(w.detach(), self.pol.lp, out_n=n[j * H:(j + 1) * H], out_t=t[:, j * H:(j + 1) * H])
+                if b is not None:
+                    ops.cast2d(b.detach().view(1, H), torch.float32, out=bias[j * H:(j + 1) * H].view(1, H))
+            return n, t, bias
+        return self._get(("qkv", id(wq)), (wq, wk, wv, bq, bk, bv), build)
+
+    def conv(self, w):
+        """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], dgrad operand [k*ci, co])."""
+        return self._get(("conv", id(w)), (w,), lambda: ops.cast_conv_weight(w.detach(), self.pol.lp))
+
+    def posconv(self, v, g):
+        """weight-normed grouped conv -> (w [G,Cg,K*Cg], flipped dgrad form, norms [K])."""
+        return self._get(("posconv", id(v)), (v, g), lambda: ops.weight_norm_fwd(v.detach(), g.detach(), self.pol.lp))
+
+
+class Ctx:
+    """What every Function needs besides tensors."""
+
+    def __init__(self, policy, cache=None):
+        self.pol = policy if isinstance(policy, Policy) else Policy(policy)
+        self.cache = cache or WeightCache(self.pol)
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def _ln_fwd(pol, x, w, b, eps, need_f32, act=0):
+    if pol.f32:
+        y32, _, mean, rstd = ops.ln_fwd(x, w, b, eps, want_f32=True, lp_dtype=None, act=act)
+        return y32, y32, mean, rstd
+    y32, ylp, mean, rstd = ops.ln_fwd(x, w, b, eps, want_f32=need_f32, lp_dtype=pol.lp, act=act)
+    return y32, ylp, mean, rstd
+
+
+def _ln_bwd(pol, dy, x, w, b, mean, rstd, dx_add=None, need_lp=True, act=0, need_f32=True):
+    if pol.f32:
+        dx32, _, dg, db = ops.ln_bwd(dy, x, w, b, mean, rstd, dx_add=dx_add, want_f32=True, lp_dtype=None, act=act)
+        return dx32, dx32, dg, db
+    return ops.ln_bwd(dy, x, w, b, mean, rstd, dx_add=dx_add, want_f32=need_f32, lp_dtype=pol.lp if need_lp else None, act=act)
+
+
+def _to_lp(pol, x32):
+    return x32 if pol.f32 else ops.cast2d(x32, pol.lp)
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------- encoder layer
+class LayerSpec:
+    def __init__(self, B, S, nheads, eps, pre_ln, mask_mode=0):
+        self.B, self.S, self.nheads, self.eps, self.pre_ln, self.mask_mode = B, S, nheads, eps, pre_ln, mask_mode
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """One transformer layer.  params = (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2).
+
+    pre_ln  (VideoMAE / fusion / wav2vec2 stable-LN; reference utils/TAVFormer.py:243-271, HF videomae:326-357, wav2vec2:611-654):
+        x1 = x + Wo.attn(LN1(x));  x2 = x1 + W2.gelu(W1.LN2(x1))
+    post_ln (BERT / RoBERTa / wav2vec2-base; HF roberta:211-398, wav2vec2:575-608):
+        x1 = LN1(x + Wo.attn(x));  x2 = LN2(x1 + W2.gelu(W1.x1))
+    Returns (x2 f32, x2_lp): the low-precision copy is a by-product for the next layer's GEMMs (not differentiable).
+    """
+
+    @staticmethod
+    def forward(ctx, x, x_lp, key_mask, ectx, spec, *params):
+        pol, cache = ectx.pol, ectx.cache
+        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
+        B, S, nh = spec.B, spec.S, spec.nheads
+        H = nh * 64
+        wqkv, _, bqkv = cache.qkv(wq, wk, wv, bq, bk, bv)
+        wo_n, _ = cache.linear(wo)
+        w1_n, _ = cache.linear(w1)
+        w2_n, _ = cache.linear(w2)
+        x = _c(x)
+        if spec.pre_ln:
+            _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
+        else:
+            a = x_lp if x_lp is not None else _to_lp(pol, x)
+            mean1 = rstd1 = None
+        qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
+        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        y1 = ops.gemm_nt(o, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
+        if spec.pre_ln:
+            x1 = y1
+            _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
+        else:
+            x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
+        h, u = ops.gemm_nt(c, w1_n, bias=b1, act=1, want_pre=True)
+        y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=x1, out_dtype=torch.float32)
+        if spec.pre_ln:
+            x2, x2_lp = y2, None
+            mean_o = rstd_o = None
+        else:
+            x2, x2_lp, mean_o, rstd_o = _ln_fwd(pol, y2, ln2_w, ln2_b, spec.eps, need_f32=True)
+            mean2, rstd2 = mean_o, rstd_o
+        ctx.ectx, ctx.spec = ectx, spec
+        ctx.has = [p is not None for p in params]
+        corr, o_soft = aux
+        ctx.save_for_backward(x if spec.pre_ln else None, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2 if not spec.pre_ln else None,
+                              mean1, rstd1, mean2, rstd2, key_mask, *params)
+        if x2_lp is None or pol.f32:
+            x2_lp = x2.new_empty(0)
+        ctx.mark_non_differentiable(x2_lp)
+        return x2, x2_lp
+
+    @staticmethod
+    def backward(ctx, g2, _g_lp):
+        pol, cache, spec = ctx.ectx.pol, ctx.ectx.cache, ctx.spec
+        sv = ctx.saved_tensors
+        x, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2, mean1, rstd1, mean2, rstd2, key_mask = sv[:17]
+        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[17:]
+        B, S, nh = spec.B, spec.S, spec.nheads
+        H = nh * 64
+        _, wqkv_t, _ = cache.qkv(wq, wk, wv, bq, bk, bv)
+        _, wo_t = cache.linear(wo)
+        _, w1_t = cache.linear(w1)
+        _, w2_t = cache.linear(w2)
+        g2 = _c(g2)
+        if spec.pre_ln:
+            dy2, dy2_lp = g2, _to_lp(pol, g2)
+            dg2 = db2 = None
+        else:
+            dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
+        # FFN
+        dW2 = ops.gemm_tn(dy2_lp, h)
+        dB2 = ops.colsum(dy2_lp)
+        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
+        dW1 = ops.gemm_tn(du, c)
+        dB1 = ops.colsum(du)
+        if spec.pre_ln:
+            dc = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)
+            g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
+            dy1, dy1_lp = g1, g1_lp
+        else:
+            g1 = ops.gemm_nt(du, w1_t, resid=dy2, out_dtype=torch.float32)
+            dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
+        # attention
+        dWo = ops.gemm_tn(dy1_lp, o)
+        dBo = ops.colsum(dy1_lp)
+        do = ops.gemm_nt(dy1_lp, wo_t)
+        dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
+                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        dWqkv = ops.gemm_tn(dqkv, a)
+        dBqkv = ops.colsum(dqkv)
+        if spec.pre_ln:
+            da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
+            g0, _, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=False)
+        else:
+            g0 = ops.gemm_nt(dqkv, wqkv_t, resid=dy1, out_dtype=torch.float32)
+        grads = [dg1, db1, dWqkv[:H], dBqkv[:H], dWqkv[H:2 * H], dBqkv[H:2 * H], dWqkv[2 * H:], dBqkv[2 * H:], dWo, dBo, dg2, db2, dW1, dB1, dW2, dB2]
+        grads = [g if has else None for g, has in zip(grads, ctx.has)]
+        return (g0, None, None, None, None, *grads)
+
+
+def encoder_layer(ectx, spec, x, x_lp, key_mask, params):
+    x2, x2_lp = EncoderLayerFn.apply(x, x_lp, key_mask, ectx, spec, *params)
+    return x2, (x2_lp if x2_lp.numel() else None)
+
+
+# ---------------------------------------------------------------------------------------------- generic pieces
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) (+ resid) with x given as its operand-dtype copy; returns f32 or lp output.
+    Used for projections outside the layer body (feature projection, wav_2_768*, pooler, patch embedding)."""
+
+    @staticmethod
+    def forward(ctx, x32, x_lp, w, b, resid, ectx, out_f32):
+        pol = ectx.pol
+        if x_lp is None:
+            x_lp = _to_lp(pol, _c(x32))
+        w_n, _ = ectx.cache.linear(w)
+        y = ops.gemm_nt(x_lp, w_n, bias=b, resid=resid, out_dtype=torch.float32 if out_f32 else pol.lp)
+        ctx.ectx = ectx
+        ctx.in_f32 = x32 is not None
+        ctx.save_for_backward(x_lp, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        pol = ctx.ectx.pol
+        x_lp, w, b = ctx.saved_tensors
+        _, w_t = ctx.ectx.cache.linear(w)
+        gy = _c(gy)
+        gy_lp = gy if gy.dtype == pol.lp else _to_lp(pol, gy)
+        dW = ops.gemm_tn(gy_lp, x_lp) if ctx.needs_input_grad[2] else None
+        dB = ops.colsum(gy_lp) if (b is not None and ctx.needs_input_grad[3]) else None
+        dx = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = ops.gemm_nt(gy_lp, w_t, out_dtype=torch.float32 if ctx.in_f32 else pol.lp)
+        d_res = gy if ctx.needs_input_grad[4] else None
+        return (dx if ctx.in_f32 else None, None if ctx.in_f32 else dx, dW, dB, d_res, None, None)
+
+
+class LayerNormF32Fn(torch.autograd.Function):
+    """f32 residual stream [rows, W] -> (y f32, y_lp by-product for the next GEMM, not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, ectx):
+        x = _c(x)
+        y32, ylp, mean, rstd = _ln_fwd(ectx.pol, x, w, b, eps, need_f32=True)
+        ctx.ectx = ectx
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        if ectx.pol.f32:
+            ylp = y32.new_empty(0)
+        ctx.mark_non_differentiable(ylp)
+        return y32, ylp
+
+    @staticmethod
+    def backward(ctx, g32, _glp):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        dx32, _, dg, db = _ln_bwd(ctx.ectx.pol, _c(g32), x, w, b, mean, rstd, need_lp=False)
+        return dx32, dg, db, None, None
+
+
+class LayerNormLpFn(torch.autograd.Function):
+    """operand-dtype activation [rows, W] -> operand-dtype output; act=1 fuses the exact GELU
+    (wav2vec2 'layer' conv blocks, HF wav2vec2:275-301; feature projection LN :422-434)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, ectx, act):
+        x = _c(x)
+        _, ylp, mean, rstd = _ln_fwd(ectx.pol, x, w, b, eps, need_f32=False, act=act)
+        ctx.ectx, ctx.act = ectx, act
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        return ylp
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        pol = ctx.ectx.pol
+        _, dxlp, dg, db = _ln_bwd(pol, _c(g), x, w, b, mean, rstd, need_lp=True, act=ctx.act, need_f32=pol.f32)
+        return dxlp, dg, db, None, None, None
+
+
+def layer_norm_f32(ectx, x, w, b, eps):
+    """Returns (y_f32, y_lp); in the fp32 policy both are the same tensor."""
+    y32, ylp = LayerNormF32Fn.apply(x, w, b, eps, ectx)
+    return y32, (y32 if ectx.pol.f32 else ylp)
+
+
+def layer_norm_lp(ectx, x, w, b, eps, act=0):
+    return LayerNormLpFn.apply(x, w, b, eps, ectx, act)
+
+
+# ---------------------------------------------------------------------------------------------- embeddings
+class EmbedAddFn(torch.autograd.Function):
+    """out = x + table[ids]   (models/tav.py:474: hidden_states + nn.Embedding(3,768)(pos_embed))."""
+
+    @staticmethod
+    def forward(ctx, x, ids, table):
+        x = _c(x)
+        ctx.save_for_backward(ids)
+        ctx.ntable = table.shape[0]
+        return ops.embed_add_fwd(x, ids, table.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        g = _c(g)
+        dt = ops.embed_add_bwd(g, ids, ctx.ntable) if ctx.needs_input_grad[2] else None
+        return g, None, dt
+
+
+class TextEmbedFn(torch.autograd.Function):
+    """HF roberta/bert embeddings (roberta:75-121): word + position + token_type[0] -> LayerNorm. Returns (y f32, y_lp)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, ln_w, ln_b, eps, pad_id, ectx):
+        pol = ectx.pol
+        y32, ylp, pre, pos_ids, mean, rstd = ops.text_embed_fwd(ids, word.detach(), pos.detach(), typ.detach(), ln_w.detach(), ln_b.detach(), eps,
+                                                                pad_id, want_f32=True, lp_dtype=None if pol.f32 else pol.lp)
+        ctx.ectx = ectx
+        ctx.shapes = (word.shape[0], pos.shape[0], typ.shape[0])
+        ctx.save_for_backward(ids, pos_ids, pre, mean, rstd, ln_w, ln_b)
+        if ylp is None:
+            ylp = y32.new_empty(0)
+        ctx.mark_non_differentiable(ylp)
+        return y32, ylp
+
+    @staticmethod
+    def backward(ctx, g, _):
+        ids, pos_ids, pre, mean, rstd, ln_w, ln_b = ctx.saved_tensors
+        dpre, _, dg, db = _ln_bwd(ctx.ectx.pol, _c(g), pre, ln_w, ln_b, mean, rstd, need_lp=False)
+        nv, npos, ntyp = ctx.shapes
+        dword = ops.scatter_add_rows(dpre, ids.reshape(-1), nv) if ctx.needs_input_grad[1] else None
+        dpos = ops.scatter_add_rows(dpre, pos_ids.reshape(-1), npos) if ctx.needs_input_grad[2] else None
+        dtyp = None
+        if ctx.needs_input_grad[3]:
+            dtyp = ops.zeros_f32((ntyp, dpre.shape[1]), dpre.device)
+            ops.colsum(dpre, out=dtyp[0])
+        return None, dword, dpos, dtyp, dg, db, None, None, None
+
+
+def text_embed(ectx, ids, word, pos, typ, ln_w, ln_b, eps, pad_id):
+    y32, ylp = TextEmbedFn.apply(ids, word, pos, typ, ln_w, ln_b, eps, pad_id, ectx)
+    return y32, (y32 if ectx.pol.f32 else ylp)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """VideoMAE tubelet embedding of the KEPT tokens only (HF videomae:94-177): Conv3d(k=s=(2,16,16)) as a GEMM over
+    gathered patches, + bias + fixed sin-cos position rows.  `embeddings[~mask]` keeps rows in ascending token order,
+    which is the order of keep_idx.  Output f32 [B*nkeep, hidden]."""
+
+    @staticmethod
+    def forward(ctx, video, keep_idx, w, b, pos_table, ectx):
+        pol = ectx.pol
+        patches = ops.patchify(_c(video), keep_idx, pol.lp)
+        w2d = w.detach().view(w.shape[0], -1)
+        w_n, _ = ectx.cache._get(("patch", id(w)), (w,), lambda: (w2d, None) if pol.f32 else (ops.cast_weight(w2d, pol.lp, want_t=False)[0], None))
+        resid = ops.gather_rows(pos_table, keep_idx.reshape(-1))
+        y = ops.gemm_nt(patches, w_n, bias=b, resid=resid, out_dtype=torch.float32)
+        ctx.ectx, ctx.wshape = ectx, tuple(w.shape)
+        ctx.save_for_backward(patches)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (patches,) = ctx.saved_tensors
+        g_lp = _to_lp(ctx.ectx.pol, _c(g))
+        dW = ops.gemm_tn(g_lp, patches).view(ctx.wshape) if ctx.needs_input_grad[2] else None
+        dB = ops.colsum(g_lp) if ctx.needs_input_grad[3] else None
+        return None, None, dW, dB, None, None
+
+
+# ---------------------------------------------------------------------------------------------- wav2vec2 front-end
+class Conv0Fn(torch.autograd.Function):
+    """Conv1d(1, C, k, stride) on the raw waveform -> channels-last [B, T_out, C] in the operand dtype (HF wav2vec2:382-419)."""
+
+    @staticmethod
+    def forward(ctx, wave, w, b, stride, ectx):
+        wave = _c(wave)
+        K = w.shape[-1]
+        T_out = (wave.shape[1] - K) // stride + 1
+        y = ops.conv0_fwd(wave, w.detach(), b.detach() if b is not None else None, T_out, stride, ectx.pol.lp)
+        ctx.stride, ctx.K, ctx.has_b = stride, K, b is not None
+        ctx.save_for_backward(wave)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (wave,) = ctx.saved_tensors
+        dw, db = ops.conv0_bwd_w(wave, _c(g), ctx.K, ctx.stride, ctx.has_b)
+        return None, dw, db, None, None
+
+
+class GroupNormGeluFn(torch.autograd.Function):
+    """GroupNorm(C groups) over time + GELU on channels-last activations (wav2vec2 'group' layer 0, HF wav2vec2:304-323)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y, stats = ops.gn_gelu_fwd(_c(x), w.detach(), b.detach(), eps)
+        ctx.save_for_backward(x, w, b, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, stats = ctx.saved_tensors
+        dx, dg, db = ops.gn_gelu_bwd(x, _c(g), w, b, stats)
+        return dx, dg, db, None
+
+
+class ConvGemmFn(torch.autograd.Function):
+    """Conv1d(C_in, C_out, k, stride) on channels-last [B, T_in, C_in] as one NT GEMM over overlapping rows
+    (lda = stride*C_in, K = k*C_in), optional bias and fused exact GELU; gradients: TN GEMM (dW), NT GEMM + col2im (dx)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, gelu, ectx):
+        x = _c(x)
+        B, T_in, Ci = x.shape
+        Co, _, k = w.shape
+        T_out = (T_in - k) // stride + 1
+        w_n, _ = ectx.cache.conv(w)
+        res = ops.gemm_nt(x, w_n, bias=b, act=1 if gelu else 0, want_pre=gelu, M=T_out, N=Co, K=k * Ci, lda=stride * Ci, ldb=k * Ci, ldc=Co,
+                          nzb=B, a_zb=T_in * Ci, c_zb=T_out * Co, out_shape=(B, T_out, Co))
+        y, pre = res if gelu else (res, None)
+        ctx.ectx, ctx.geom, ctx.has_b = ectx, (B, T_in, Ci, Co, k, stride, T_out), b is not None
+        ctx.save_for_backward(x, w, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, pre = ctx.saved_tensors
+        B, T_in, Ci, Co, k, stride, T_out = ctx.geom
+        g = _c(g)
+        du = ops.gelu_bwd(pre, g) if pre is not None else g
+        _, w_t = ctx.ectx.cache.conv(w)
+        dw = db = dx = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(du, x, N1=Co, N2=k * Ci, lda=Co, ldb=stride * Ci, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Co, b_zb=T_in * Ci,
+                             perm_inner=Ci, perm_outer=k, out_shape=(Co, Ci, k))
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(du.view(B * T_out, Co))
+        if ctx.needs_input_grad[0]:
+            dcol = ops.gemm_nt(du.view(B * T_out, Co), w_t, out_shape=(B * T_out, k * Ci))
+            dx = ops.col2im_1d(dcol, B, T_in, T_out, Ci, k, stride)
+        return dx, dw, db, None, None, None
+
+
+class PosConvFn(torch.autograd.Function):
+    """hidden + gelu(grouped Conv1d(H, H, k=128, pad=64, groups=16)(hidden)[..., :-1]) with weight-norm (dim=2) parameters
+    (HF wav2vec2:326-379, used at :758-759/:833-834 and reference models/tav.py:360).  f32 residual in, f32 out."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, B, T, G, ectx):
+        pol = ectx.pol
+        x = _c(x)
+        H = x.shape[1]
+        Cg, K = H // G, v.shape[2]
+        w, _, norms = ectx.cache.posconv(v, g)
+        pad = K // 2
+        xg = ops.group_pad(x, B, T, H, G, pad, pad, pol.lp)
+        TP = T + 2 * pad
+        y, pre = ops.gemm_nt(xg, w, bias=bias, act=1, resid=x, want_pre=True, out_dtype=torch.float32, M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg,
+                             ldc=H, nzb=B, nzg=G, a_zb=G * TP * Cg, a_zg=TP * Cg, b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, bias_zg=Cg,
+                             out_shape=(B * T, H))
+        ctx.ectx, ctx.geom = ectx, (B, T, H, G, Cg, K)
+        ctx.save_for_backward(xg, pre, v, g, norms)
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        xg, pre, v, g, norms = ctx.saved_tensors
+        pol = ctx.ectx.pol
+        B, T, H, G, Cg, K = ctx.geom
+        gout = _c(gout)
+        _, wf, _ = ctx.ectx.cache.posconv(v, g)
+        du = ops.gelu_bwd(pre, gout)                                   # f32 [B*T, H]
+        pad = K // 2
+        dug = ops.group_pad(du, B, T, H, G, pad - 1, pad, pol.lp)      # flipped-kernel form of the input gradient
+        TPd, TP = T + 2 * pad - 1, T + 2 * pad
+        dx = ops.gemm_nt(dug, wf, resid=gout, out_dtype=torch.float32, M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg, ldc=H, nzb=B, nzg=G,
+                         a_zb=G * TPd * Cg, a_zg=TPd * Cg, b_zg=Cg * K * Cg, c_zb=T * H, c_zg=Cg, out_shape=(B * T, H))
+        du_lp = _to_lp(pol, du)
+        dw = torch.empty(G, Cg, K * Cg, dtype=torch.float32, device=du.device)
+        for gi in range(G):
+            ops.gemm_tn(du_lp[:, gi * Cg:], xg[:, gi], out=dw[gi], N1=Cg, N2=K * Cg, lda=H, ldb=Cg, rows_per_batch=T, nbatch=B, a_zb=T * H,
+                        b_zb=G * TP * Cg)
+        dv, dg = ops.weight_norm_bwd(v, g, norms, dw)
+        dbias = ops.colsum(du)
+        return dx, dv, dg.view_as(g), dbias, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- sequence concat / pooling / tail
+class ConcatSeqFn(torch.autograd.Function):
+    """torch.concat(parts, dim=1) for [B, S_i, W] f32 parts (models/tav.py:372)."""
+
+    @staticmethod
+    def forward(ctx, B, *parts):
+        W = parts[0].shape[-1]
+        lens = [p.numel() // (B * W) for p in parts]
+        Sf = sum(lens)
+        out = torch.empty(B, Sf, W, dtype=torch.float32, device=parts[0].device)
+        flat = out.view(B, Sf * W)
+        off = 0
+        for p, L in zip(parts, lens):
+            ops.cast2d(_c(p).view(B, L * W), torch.float32, out=flat[:, off * W:(off + L) * W])
+            off += L
+        ctx.lens, ctx.W, ctx.B = lens, W, B
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, W = ctx.B, ctx.W
+        flat = _c(g).view(B, -1)
+        outs, off = [], 0
+        for L in ctx.lens:
+            outs.append(ops.cast2d(flat[:, off * W:(off + L) * W], torch.float32).view(B * L, W))
+            off += L
+        return (None, *outs)
+
+
+class TailFn(torch.autograd.Function):
+    """models/tav.py:478-499: mean-pool the audio/video/fusion streams, four LayerNorms, concat [av, t, aud, vid] -> [B,3072],
+    optional dropout (check == 'train'), Linear(3072, output_dim).  All f32 (tiny tensors)."""
+
+    @staticmethod
+    def forward(ctx, av_seq, t_pooled, aud_seq, vid_seq, B, S_av, S_aud, S_vid, p_drop, seed, rand_w, rand_b, bert_w, bert_b, aud_w, aud_b,
+                vid_w, vid_b, lin_w, lin_b):
+        W = 768
+        pooled = [ops.mean_pool_fwd(_c(av_seq), B, S_av), _c(t_pooled), ops.mean_pool_fwd(_c(aud_seq), B, S_aud), ops.mean_pool_fwd(_c(vid_seq), B, S_vid)]
+        norms = [(rand_w, rand_b), (bert_w, bert_b), (aud_w, aud_b), (vid_w, vid_b)]
+        cat = torch.empty(B, 4 * W, dtype=torch.float32, device=av_seq.device)
+        stats = []
+        for j, (x, (w, b)) in enumerate(zip(pooled, norms)):
+            y32, _, mean, rstd = ops.ln_fwd(x, w.detach(), b.detach(), 1e-5, want_f32=True)
+            ops.cast2d(y32, torch.float32, out=cat[:, j * W:(j + 1) * W])
+            stats += [mean, rstd]
+        mask = None
+        feat = cat
+        if p_drop > 0.0:
+            feat, mask = ops.dropout_fwd(cat, p_drop, seed, 0)
+        logits = ops.head_fwd(feat, lin_w.detach(), lin_b.detach())
+        ctx.geom = (B, S_av, S_aud, S_vid, p_drop)
+        ctx.save_for_backward(feat, mask, lin_w, *pooled, *stats, rand_w, rand_b, bert_w, bert_b, aud_w, aud_b, vid_w, vid_b)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S_av, S_aud, S_vid, p_drop = ctx.geom
+        sv = ctx.saved_tensors
+        feat, mask, lin_w = sv[:3]
+        pooled, stats, nw = sv[3:7], sv[7:15], sv[15:23]
+        W = 768
+        dfeat, dW, db = ops.head_bwd(feat, lin_w, _c(g))
+        if mask is not None:
+            dfeat = ops.dropout_bwd(dfeat, mask, p_drop)
+        dpool, dparams = [], []
+        for j in range(4):
+            dy = ops.cast2d(dfeat[:, j * W:(j + 1) * W], torch.float32)
+            dx, _, dg, dbt = ops.ln_bwd(dy, pooled[j], nw[2 * j], nw[2 * j + 1], stats[2 * j], stats[2 * j + 1], want_f32=True)
+            dpool.append(dx)
+            dparams += [dg, dbt]
+        d_av, _ = ops.mean_pool_bwd(dpool[0], B, S_av)
+        d_aud, _ = ops.mean_pool_bwd(dpool[2], B, S_aud)
+        d_vid, _ = ops.mean_pool_bwd(dpool[3], B, S_vid)
+        return (d_av, dpool[1], d_aud, d_vid, None, None, None, None, None, None, *dparams, dW, db)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss (optionally class-weighted), mean reduction (utils/global_functions.py:63-64)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        loss, dlog = ops.cross_entropy(_c(logits), target, weight)
+        ctx.save_for_backward(dlog)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None, None

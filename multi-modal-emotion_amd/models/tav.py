@@ -1,0 +1,243 @@
+"""Drop-in for the reference's models/tav.py model classes, executed by libtavhip on MI355X.
+
+  PreFormer   reference models/tav.py:249-417   modality front-ends -> fused token sequence + masks
+  TAVForMAE   reference models/tav.py:420-504   3 encoders + fusion encoder + 7-way head
+  collate_batch  reference models/tav.py:174-246   (mask / pad logic only: file decoding is out of scope)
+
+Same constructor arguments, forward() signatures and state_dict keys.  `from_pretrained` checkpoints are not
+reachable offline, so sub-models are built from a geometry preset (config.py) and initialised randomly; load a
+reference `best.pt` with `load_state_dict(remap_reference_keys(sd))`.
+The reference keeps PreFormer on the CPU and ships activations back and forth (models/tav.py:352,359,363); here every
+tensor stays resident in HBM: inputs given on the CPU are moved to the GPU once, outputs are returned on the GPU
+(the reference's `.to(device)` calls in tav_train.py:39-40 then cost nothing).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import config as C
+from .. import engine as E
+from .. import runtime
+from ..encoders import AudioEncoder, TextEncoder, VideoEncoder
+from ..utils.TAVFormer import VideoMAEEncoder
+
+FP16_MIN = float(torch.finfo(torch.float16).min)
+
+
+def _dev(device):
+    d = torch.device(device if device is not None else "cuda")
+    if d.type != "cuda":
+        d = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else d
+    if d.type != "cuda":
+        raise RuntimeError("the TAV hot path runs on libtavhip (HIP, MI355X) only: no GPU is visible and there is no CPU fallback")
+    return d
+
+
+class PreFormer(nn.Module):
+    """Modality front-ends (reference models/tav.py:249-417)."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        cfg = config if config is not None else C.default_config()
+        self.cfg = cfg
+        Ha = cfg["audio"]["hidden"]
+        self.bert = TextEncoder(cfg["text"])
+        self.wav2vec2 = AudioEncoder(cfg["audio"])
+        self.masked_spec_embed = nn.Parameter(torch.FloatTensor(Ha).uniform_())
+        self.videomae = VideoEncoder(cfg["video"])
+        self.wav_2_768 = nn.Linear(Ha, 768)
+        nn.init.xavier_normal_(self.wav_2_768.weight)
+        self.check_shapes = 1
+
+    # -- reference helpers, same names (models/tav.py:308-342) --
+    def _get_feat_extract_output_lengths(self, input_lengths, add_adapter=None):
+        for k, s in zip(self.cfg["audio"]["conv_kernel"], self.cfg["audio"]["conv_stride"]):
+            input_lengths = torch.div(input_lengths - k, s, rounding_mode="floor") + 1
+        return input_lengths
+
+    def _get_feature_vector_attention_mask(self, feature_vector_length, attention_mask, add_adapter=None):
+        non_padded = attention_mask.cumsum(dim=-1)[:, -1]
+        out_len = self._get_feat_extract_output_lengths(non_padded).to(torch.long)
+        B = attention_mask.shape[0]
+        m = torch.zeros((B, feature_vector_length), dtype=attention_mask.dtype, device=attention_mask.device)
+        m[(torch.arange(B, device=m.device), out_len - 1)] = 1
+        return m.flip([-1]).cumsum(-1).flip([-1]).bool()
+
+    def _mask_hidden_states(self, hidden, B, T, attention_mask, training=False):
+        """SpecAugment along time (models/tav.py:269-306).  Host-side index sampling as in the reference (numpy RNG);
+        only active when train=True, which is outside the parity / benchmark configuration."""
+        mask_prob, mask_len = 0.05, 10                      # Wav2Vec2Config defaults (mask_time_prob / mask_time_length)
+        if not training or T < mask_len:
+            return hidden
+        from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+        idx = _compute_mask_indices((B, T), mask_prob=mask_prob, mask_length=mask_len, attention_mask=attention_mask.cpu(), min_masks=2)
+        sel = torch.tensor(idx, device=hidden.device, dtype=torch.bool).reshape(B * T, 1)
+        return torch.where(sel, self.masked_spec_embed.to(hidden.dtype)[None, :], hidden)
+
+    def forward(self, input_ids=None, audio_features=None, video_embeds=None, text_mask=None, audio_mask=None, visual_mask=None,
+                device="cpu", train=False, n_visual_true=None):
+        """n_visual_true (optional): number of True entries per row of visual_mask; passing it avoids one host sync."""
+        dev = _dev(device if str(device) != "cpu" else None)
+        ectx = runtime.ctx()
+        B = audio_features.shape[0]
+        parts = []
+        St = 0
+        if input_ids is not None:
+            input_ids = input_ids.to(dev)
+            x_text, _ = self.bert.embed(input_ids)                                      # :349
+            St = input_ids.shape[1]
+            parts.append(x_text)
+        feats = self.wav2vec2.feature_extractor_fwd(audio_features.to(dev, torch.float32))   # :352  [B, Sa, 512]
+        Sa = feats.shape[1]
+        if audio_mask is not None:
+            audio_mask = self._get_feature_vector_attention_mask(Sa, audio_mask.to(dev))     # :355 bool [B, Sa]
+        hidden = self.wav2vec2.feature_projection_fwd(feats)                            # :356  f32 [B*Sa, Ha]
+        hidden = self._mask_hidden_states(hidden, B, Sa, audio_mask, train)             # :359
+        hidden = self.wav2vec2.pos_conv_fwd(hidden, B, Sa)                              # :360
+        enc = self.wav2vec2.encoder
+        hidden, hidden_lp = E.layer_norm_f32(ectx, hidden, enc.layer_norm.weight, enc.layer_norm.bias, self.cfg["audio"]["eps"])   # :361
+        x_audio = E.LinearFn.apply(hidden, hidden_lp if not ectx.pol.f32 else None, self.wav_2_768.weight, self.wav_2_768.bias, None, ectx, True)   # :363
+        parts.append(x_audio)
+        visual_mask = visual_mask.to(dev)
+        x_video, Nv = self.videomae.embed(video_embeds.to(dev, torch.float32), ~visual_mask, n_visual_true)   # :368
+        parts.append(x_video)
+        tav = E.ConcatSeqFn.apply(B, *parts)                                            # :372-375
+
+        # static modality ids and masks (:378-409) -- tiny host-logic tensors
+        pos = [torch.zeros((B, St), device=dev)] if input_ids is not None else []
+        pos += [torch.ones((B, Sa), device=dev), torch.ones((B, Nv), device=dev) + 1]
+        tav_embed = torch.concat(pos, dim=1).type(torch.long)
+        masks = []
+        if input_ids is not None and text_mask is not None:
+            masks.append((1.0 - text_mask.to(dev)[:, None, None, :]) * FP16_MIN)        # :383
+        if audio_mask is not None:
+            masks.append(1.0 - audio_mask[:, None, None, :] * FP16_MIN)                 # :390 (precedence as written)
+        masks.append(torch.zeros((B, 1, 1, Nv), device=dev, dtype=torch.float))         # :397
+        attention_mask = torch.concat(masks, dim=-1)                                    # :409
+        if self.check_shapes == 1:
+            self.check_shapes += 1
+            print(f"Text shape is {(B, St, 768)}\nAudio shape is {(B, Sa, 768)}\nVideo shape is {(B, Nv, 768)}\n", flush=True)
+        return tav, tav_embed, attention_mask
+
+
+class TAVForMAE(nn.Module):
+    """Tri-modal classifier (reference models/tav.py:420-504)."""
+
+    def __init__(self, args, config=None):
+        super().__init__()
+        cfg = config if config is not None else C.default_config()
+        self.cfg = cfg
+        self.output_dim = args["output_dim"]
+        self.dropout_p = float(args["dropout"])
+        self.learn_PosEmbeddings = args["learn_PosEmbeddings"]
+        self.num_layers = args["num_layers"]            # stored, unused: the fusion depth is fixed (reference :430,442)
+        Ha = cfg["audio"]["hidden"]
+        self.test_ctr = 1
+        self.train_ctr = 1
+        self.embedding = nn.Embedding(3, 768)
+        self.embedding.weight.requires_grad = bool(self.learn_PosEmbeddings)
+        self.bert = TextEncoder(cfg["text"])
+        self.bert_norm = nn.LayerNorm(768)
+        self.random_mae_config = dict(cfg["fusion"])
+        self.random_mae_encoder = VideoMAEEncoder(self.random_mae_config, cfg["fusion"]["layers"]).apply(self.randomize_model)
+        self.rand_norm = nn.LayerNorm(768)
+        self.vid_norm = nn.LayerNorm(768)
+        self.aud_norm = nn.LayerNorm(768)
+        self.linear1 = nn.Linear(768 * 4, self.output_dim)
+        self.wav2vec2 = AudioEncoder(cfg["audio"])
+        self.videomae = VideoEncoder(cfg["video"])
+        self.wav_2_768_2 = nn.Linear(Ha, 768)
+        nn.init.xavier_normal_(self.wav_2_768_2.weight)
+        self._drop_calls = 0
+
+    def randomize_model(self, model):
+        """reference :461-471: xavier_uniform Linear/Embedding weights, zero biases, LayerNorm weight = 1 / bias = 0."""
+        for _, m in model.named_modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.xavier_uniform_(m.weight)
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight.data.fill_(1.0)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+        return model
+
+    def forward(self, input_ids, text_attention_mask, audio_features, video_embeds, visual_mask, hidden_states, pos_embed, attention_mask,
+                batch_size=2, check="train", n_visual_true=None):
+        dev = _dev(hidden_states.device if hidden_states.is_cuda else None)
+        B, Sf, _ = hidden_states.shape
+        av = E.EmbedAddFn.apply(hidden_states.to(dev).reshape(B * Sf, 768), pos_embed.to(dev).reshape(-1).contiguous(), self.embedding.weight)   # :474
+        aud, aud_lp, Sa = self.wav2vec2(audio_features.to(dev, torch.float32))          # :476
+        ectx = runtime.ctx()
+        aud = E.LinearFn.apply(aud, aud_lp if not ectx.pol.f32 else None, self.wav_2_768_2.weight, self.wav_2_768_2.bias, None, ectx, True)   # :478
+        nkeep = None if n_visual_true is None else visual_mask.shape[1] - n_visual_true
+        vid, Sv = self.videomae(video_embeds.to(dev, torch.float32), visual_mask.to(dev), nkeep)    # :480
+        _, t = self.bert(input_ids.to(dev), text_attention_mask.to(dev))                # :485
+        av = self.random_mae_encoder(av.view(B, Sf, 768), attention_mask.to(dev))       # :487
+        p_drop = self.dropout_p if check == "train" else 0.0
+        self._drop_calls += 1
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & 0xFFFFFFFFFFFFFFFF
+        return E.TailFn.apply(av.reshape(B * Sf, 768), t, aud, vid, B, Sf, Sa, Sv, p_drop, seed,
+                              self.rand_norm.weight, self.rand_norm.bias, self.bert_norm.weight, self.bert_norm.bias,
+                              self.aud_norm.weight, self.aud_norm.bias, self.vid_norm.weight, self.vid_norm.bias,
+                              self.linear1.weight, self.linear1.bias)                   # :486-499
+
+
+def remap_reference_keys(state_dict):
+    """Key names of a checkpoint saved with transformers 4.2x -> this package (transformers >= 5 naming), SURVEY.md §8b:
+    VideoMAE `attention.attention.q_bias / v_bias` -> `query.bias / value.bias` (+ zero key.bias) inside `videomae.*`;
+    weight-norm `weight_g / weight_v` -> `parametrizations.weight.original0 / original1`."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("videomae.") and k.endswith(".attention.attention.q_bias"):
+            base = k[: -len("q_bias")]
+            out[base + "query.bias"] = v
+            out[base + "key.bias"] = torch.zeros_like(v)
+        elif k.startswith("videomae.") and k.endswith(".attention.attention.v_bias"):
+            out[k[: -len("v_bias")] + "value.bias"] = v
+        elif k.endswith("pos_conv_embed.conv.weight_g"):
+            out[k[: -len("weight_g")] + "parametrizations.weight.original0"] = v
+        elif k.endswith("pos_conv_embed.conv.weight_v"):
+            out[k[: -len("weight_v")] + "parametrizations.weight.original1"] = v
+        elif k.endswith("embeddings.position_ids"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def collate_batch(batch, check):
+    """Batch assembly contract of reference models/tav.py:174-246 for ALREADY DECODED items
+    ([{'input_ids','attention_mask'}, waveform 1-D tensor, video [16,3,224,224] (or [3,16,H,W])], label).
+    Reproduces: random video token mask True w.p. 1/15 (:207-209) then flips so every row keeps the same number of False
+    (the reference only equalises the total, which breaks batch>1 -- SURVEY.md 'Hard parts'); zero padding of audio with a
+    0/1 mask (:225-228); labels as float tensor."""
+    texts, masks, speech, vids, labels = [], [], [], [], []
+    for (inp, label) in batch:
+        texts.append(torch.as_tensor(inp[0]["input_ids"]).reshape(-1))
+        masks.append(torch.as_tensor(inp[0]["attention_mask"]).reshape(-1).float())
+        speech.append(torch.as_tensor(inp[1]).float().reshape(-1))
+        v = torch.as_tensor(inp[2]).float()
+        vids.append(v if v.shape[1] == 3 else v.permute(1, 0, 2, 3))
+        labels.append(label)
+    B = len(labels)
+    ntok = (vids[0].shape[0] // 2) * (vids[0].shape[2] // 16) * (vids[0].shape[3] // 16)
+    vid_mask = torch.randint(-13, 2, (B, ntok))
+    vid_mask[vid_mask < 0] = 0
+    vid_mask = vid_mask.bool()
+    target = int(vid_mask.sum(1).max().item())
+    for b in range(B):                                   # equal per-row counts (needed for reshape(B,-1,C) semantics)
+        short = target - int(vid_mask[b].sum().item())
+        if short > 0:
+            idx = torch.where(~vid_mask[b])[0]
+            vid_mask[b, idx[torch.randperm(len(idx))[:short]]] = True
+    T = max(len(s) for s in speech)
+    audio = torch.zeros(B, T)
+    amask = torch.zeros(B, T)
+    for b, s in enumerate(speech):
+        audio[b, : len(s)] = s
+        amask[b, : len(s)] = 1
+    text = {"input_ids": torch.stack(texts).long(), "attention_mask": torch.stack(masks)}
+    audio_features = {"audio_features": audio, "attention_mask": amask}
+    visual = {"visual_embeds": torch.stack(vids), "attention_mask": vid_mask}
+    return [text, audio_features, visual], torch.Tensor(np.array(labels))

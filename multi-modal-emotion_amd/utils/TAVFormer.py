@@ -1,0 +1,98 @@
+"""Drop-in for the reference's utils/TAVFormer.py: the two fusion encoder stacks, same constructor arguments, forward
+signatures and state_dict keys, executed by libtavhip (HIP/gfx950) instead of eager ATen.
+
+  VideoMAEEncoder(config, num_layers)   reference utils/TAVFormer.py:171-439  (the fusion encoder TAVForMAE uses;
+        pre-LN blocks; the additive attention_mask [B,1,1,S] is applied AFTER the softmax, :372-375)
+  TransformerEncoder(embed_dim, ...)    reference utils/TAVFormer.py:10-166   (post-LN alternative stack; mask BEFORE softmax)
+"""
+import torch
+from torch import nn
+
+from .. import engine as E
+from .. import runtime
+
+
+def _cfg_get(config, name, default=None):
+    if isinstance(config, dict):
+        return config.get(name, default)
+    return getattr(config, name, default)
+
+
+def _holder(**children):
+    m = nn.Module()
+    for k, v in children.items():
+        setattr(m, k, v)
+    return m
+
+
+class VideoMAESelfAttention(nn.Module):
+    """Parameter holder with the reference's names (:312-341): bias-free query/key/value + q_bias / v_bias."""
+
+    def __init__(self, hidden, qkv_bias=True):
+        super().__init__()
+        self.query = nn.Linear(hidden, hidden, bias=False)
+        self.key = nn.Linear(hidden, hidden, bias=False)
+        self.value = nn.Linear(hidden, hidden, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(hidden))
+            self.v_bias = nn.Parameter(torch.zeros(hidden))
+        else:
+            self.q_bias = None
+            self.v_bias = None
+
+
+class VideoMAELayer(nn.Module):
+    def __init__(self, hidden, inter, eps, qkv_bias=True):
+        super().__init__()
+        self.layernorm_before = nn.LayerNorm(hidden, eps=eps)
+        self.attention = _holder(attention=VideoMAESelfAttention(hidden, qkv_bias), output=_holder(dense=nn.Linear(hidden, hidden)))
+        self.layernorm_after = nn.LayerNorm(hidden, eps=eps)
+        self.intermediate = _holder(dense=nn.Linear(hidden, inter))
+        self.output = _holder(dense=nn.Linear(inter, hidden))
+
+    def params(self):
+        a = self.attention.attention
+        return (self.layernorm_before.weight, self.layernorm_before.bias, a.query.weight, a.q_bias, a.key.weight, None, a.value.weight, a.v_bias,
+                self.attention.output.dense.weight, self.attention.output.dense.bias, self.layernorm_after.weight, self.layernorm_after.bias,
+                self.intermediate.dense.weight, self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias)
+
+
+class VideoMAEEncoder(nn.Module):
+    def __init__(self, config, num_layers: int) -> None:
+        super().__init__()
+        self.config = config
+        hidden = _cfg_get(config, "hidden_size", _cfg_get(config, "hidden", 768))
+        self.num_heads = _cfg_get(config, "num_attention_heads", _cfg_get(config, "heads", 12))
+        inter = _cfg_get(config, "intermediate_size", _cfg_get(config, "inter", 3072))
+        self.eps = _cfg_get(config, "layer_norm_eps", _cfg_get(config, "eps", 1e-12))
+        qkv_bias = _cfg_get(config, "qkv_bias", True)
+        if hidden != self.num_heads * 64:
+            raise ValueError("libtavhip attention is built for head_dim 64")
+        self.layer = nn.ModuleList([VideoMAELayer(hidden, inter, self.eps, qkv_bias) for _ in range(num_layers)])
+        self.gradient_checkpointing = False
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, output_attentions: bool = False, output_hidden_states: bool = False,
+                return_dict: bool = True):
+        if head_mask is not None or output_attentions:
+            raise NotImplementedError("head_mask / output_attentions are never used on the TAV path (reference tav_train.py) and are not built")
+        if not hidden_states.is_cuda:
+            raise RuntimeError("VideoMAEEncoder runs on libtavhip (GPU) only; there is no CPU fallback")
+        ectx = runtime.ctx()
+        B, S, H = hidden_states.shape
+        key_mask, mode = None, 0
+        if attention_mask is not None:
+            key_mask = attention_mask.reshape(B, S).to(torch.float32).contiguous()      # [B,1,1,S] broadcast over heads and queries
+            mode = 2
+        spec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode)
+        x = hidden_states.reshape(B * S, H)
+        all_hidden = () if output_hidden_states else None
+        for layer in self.layer:
+            if output_hidden_states:
+                all_hidden = all_hidden + (x.view(B, S, H),)
+            x, _ = E.encoder_layer(ectx, spec, x, None, key_mask, layer.params())
+        out = x.view(B, S, H)
+        if output_hidden_states:
+            all_hidden = all_hidden + (out,)
+        if not return_dict:
+            return tuple(v for v in [out, all_hidden] if v is not None)
+        return out
