@@ -1,0 +1,210 @@
+"""Benchmark of the TAV hot path on MI355X: utterances/s of the full training step
+(PreFormer.forward -> TAVForMAE.forward(check="val") -> CE -> backward [-> gradient all-reduce] -> clip_grad_norm_ -> AdamW)
+on synthetic MELD-shaped batches (text 128 tokens, audio 16 kHz x 5 s, video 16x3x224x224, 104 fusion / 1464 encoder video tokens),
+preset B (bert-base + wav2vec2-base + videomae-base), bf16 operands / f32 accumulate, batch 8 per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (gemm_nt, bf16 MFMA): algorithmic FLOPs / launch time measured live with HIP events
+                  on the launch stream in a separate instrumented pass (the timed region itself is not instrumented);
+  cpu_baseline -- the CPU oracle (oracle/tav_oracle.py, fp32 PyTorch restatement of the reference path, kind "port") timed
+                  on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import tav_amd  # noqa: E402,F401
+from tav_amd import config as C  # noqa: E402
+from tav_amd import ops, runtime, synthetic  # noqa: E402
+from tav_amd.models.tav import PreFormer, TAVForMAE  # noqa: E402
+from tav_amd.train_model.tav_train import TrainStep  # noqa: E402
+from tav_amd.utils.global_functions import CrossEntropyLoss  # noqa: E402
+
+MFMA_PEAK_BF16_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic forward FLOPs per utterance, BASELINE.md §2 (fwd+bwd = 3x)
+FWD_GFLOP_PER_UTT = {"B": 547.0, "A": 634.8}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, pre, model, sample_b, iters):
+    """Oracle (CPU port of the reference path) fwd + loss + bwd, utterances/s on the host cores of this box."""
+    from oracle import tav_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    (tx, au, vi), lab = synthetic.make_batch(cfg, sample_b, seed=4321)
+    batch = dict(input_ids=tx["input_ids"], text_mask=tx["attention_mask"], audio_features=au["audio_features"], audio_mask=au["attention_mask"],
+                 video_embeds=vi["visual_embeds"], visual_mask=vi["attention_mask"])
+    sd_pre = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+    sd_model = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        _, loss = O.tav_step(sd_model, sd_pre, cfg, batch, lab.long())
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        log(f"cpu baseline iter {it}: {times[-1]:.2f} s (batch {sample_b}, {cores} threads)")
+        for v in list(sd_pre.values()) + list(sd_model.values()):
+            v.grad = None
+        if it >= 1 and sum(times) > 40.0:          # bounded sample
+            break
+    iters = len(times) - 1
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(sample_b / t, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 (PyTorch CPU) fwd+loss+bwd, same preset and input shapes, batch {sample_b}, median of {iters} after 1 warm-up"}
+
+
+def host_cores():
+    """CPU threads this process may really use: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    # a one-GPU box of this pool shares its host: 16 CPU threads per GPU (task environment notes)
+    return int(os.environ.get("TAV_CPU_THREADS", min(n, 16)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--preset", default="B")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libtavhip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    if args.gpus != world:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+
+    cfg = C.preset(args.preset)
+    runtime.set_precision(args.dtype)
+    b = args.batch_per_gpu
+    torch.manual_seed(0)
+    pre = PreFormer(cfg)
+    model = TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)       # identical replicas on every rank
+    torch.set_num_threads(min(host_cores(), 16))
+    log(f"[rank {rank}] models built ({sum(p.numel() for p in model.parameters()) / 1e6:.0f} M + {sum(p.numel() for p in pre.parameters()) / 1e6:.0f} M params)")
+    pre.to(dev)
+    model.to(dev)
+    inp, labels = synthetic.make_batch(cfg, b, seed=1234 + rank, device=dev)      # resident in HBM before timing
+    n_true = 104 if cfg["video"]["image"] == 224 else 4
+    stepper = TrainStep(model, pre, CrossEntropyLoss(), lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=args.bucket_mb,
+                        reduce_dtype=torch.bfloat16 if args.reduce_bf16 else None)
+
+    def one_step():
+        loss = stepper.forward_backward(inp, labels, check="val", epoch=0, n_visual_true=n_true)
+        if args.no_optimizer:
+            stepper.opt.zero_grad()
+        else:
+            stepper.update()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = one_step()
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] warm-up step {i} done")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    log(f"[rank {rank}] timed region: {elapsed / args.steps * 1e3:.2f} ms/step, loss {final_loss:.5f}")
+
+    roof = None
+    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
+        ops.profile_start("gemm_nt")
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        flops, secs, launches = ops.profile_stop()
+        ach = flops / secs / 1e12
+        roof = {"kernel": "tav::gemm_nt_kernel<bf16,*>", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": launches // 2,
+                "avg_launch_us": round(secs / launches * 1e6, 2), "share_of_step_time": round(secs / 2 / (elapsed / args.steps), 3)}
+
+    cpu_ref = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        t0 = time.time()
+        cpu_ref = cpu_baseline(cfg, pre, model, args.cpu_sample_batch, args.cpu_iters)
+        log(f"cpu baseline: {cpu_ref}  ({time.time() - t0:.1f} s)")
+
+    if rank == 0:
+        utt = world * b * args.steps
+        value = utt / elapsed
+        base = args.preset.split("-")[0]
+        step_flops = 3 * FWD_GFLOP_PER_UTT.get(base, 0.0) * 1e9 * b
+        out = {
+            "metric": "utterances/sec fwd+bwd, TAV (BERT+Wav2Vec2+VideoMAE) b=32, 1/2/4/8 MI355X",
+            "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"tav_nn.py TAV preset {args.preset} (bert-base + wav2vec2-base + videomae-base), batch {b} per GPU, text 128 tok, "
+                                   f"audio 80000 samples, video 16x3x224x224 (104 fusion / 1464 encoder tokens)",
+                       "global_batch": world * b, "per_gpu_batch": b, "parallelism": f"dp{world}",
+                       "step": "PreFormer+TAVForMAE fwd, CE, bwd" + (", grad all-reduce (RCCL)" if world > 1 else "")
+                               + ("" if args.no_optimizer else ", clip_grad_norm_, AdamW"),
+                       "weights": "random init (seeded), no checkpoints offline", "final_loss": round(final_loss, 5),
+                       "mfma_util_whole_step": round(step_flops / (elapsed / args.steps) / (MFMA_PEAK_BF16_TFLOPS * 1e12), 4)},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu_ref is not None:
+            out["cpu_baseline"] = cpu_ref
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

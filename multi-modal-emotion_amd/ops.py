@@ -26,6 +26,24 @@ def clear_workspaces():
     _ws.clear()
 
 
+# Optional live timing of one kernel family with HIP events on the launch stream (bench.py's roofline pass only).
+_prof = None
+
+
+def profile_start(kind):
+    global _prof
+    _prof = {"kind": kind, "ev": []}
+
+
+def profile_stop():
+    """-> (algorithmic FLOPs, seconds inside the kernels, launches) since profile_start()."""
+    global _prof
+    torch.cuda.synchronize()
+    ev, _prof = _prof["ev"], None
+    secs = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) * 1e-3
+    return sum(f for _, _, f in ev), secs, len(ev)
+
+
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None, want_pre=False, out=None,
             accumulate=False, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
@@ -57,7 +75,14 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
         assert resid.dtype == torch.float32
     if gelu_in is not None:
         assert gelu_in.dtype == a.dtype
-    check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
+    if _prof is not None and _prof["kind"] == "gemm_nt" and a.dtype == torch.bfloat16:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
+        e1.record()
+        _prof["ev"].append((e0, e1, 2.0 * M * N * K * max(nzb, 1) * max(nzg, 1)))
+    else:
+        check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return (out, pre) if want_pre else out
 
 

@@ -1,0 +1,99 @@
+"""Optimiser side of the step (reference train_model/tav_train.py:61-62,148): global-norm clipping + AdamW as
+multi-tensor HIP kernels driven by device pointer tables -- two launches for the norm, one for the update, no host
+synchronisation (the clip coefficient stays on the device)."""
+import ctypes as C
+
+import torch
+
+from . import engine
+from ._lib import check, lib, ptr, stream
+
+
+class _PtrTable:
+    """Pinned host staging + device array of int64 (pointers / sizes), refreshed with an async copy."""
+
+    def __init__(self, n, device):
+        self.host = torch.empty(n, dtype=torch.int64).pin_memory()
+        self.dev = torch.empty(n, dtype=torch.int64, device=device)
+
+    def set(self, values):
+        n = len(values)
+        self.host[:n].copy_(torch.tensor(values, dtype=torch.int64))
+        self.dev[:n].copy_(self.host[:n], non_blocking=True)
+        return self.dev
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt) for every parameter that
+    has a gradient at step() time; parameters whose .grad is None are skipped like torch does."""
+
+    def __init__(self, params, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.state = {}
+        self.step_count = 0
+        self._tables = None
+        self.last_norm = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def _active(self):
+        return [p for p in self.params if p.grad is not None]
+
+    def _ensure(self, act):
+        dev = act[0].device
+        n = len(act)
+        if self._tables is None or self._tables[0].host.numel() < n:
+            self._tables = tuple(_PtrTable(max(n, len(self.params)), dev) for _ in range(5))
+            self._scal = torch.zeros(4, dtype=torch.float32, device=dev)
+        for p in act:
+            if p not in self.state:
+                self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
+
+    def clip_and_step(self, max_norm=None):
+        """clip_grad_norm_(params, max_norm) (if max_norm) followed by one AdamW step.  Returns the device scalar holding
+        the total gradient norm (read it with .item() only when you need it on the host)."""
+        act = self._active()
+        if not act:
+            return None
+        self._ensure(act)
+        for p in act:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        tp, tg, tm, tv, ts = self._tables
+        n = len(act)
+        d_p = tp.set([p.data_ptr() for p in act])
+        d_g = tg.set([p.grad.data_ptr() for p in act])
+        d_m = tm.set([self.state[p][0].data_ptr() for p in act])
+        d_v = tv.set([self.state[p][1].data_ptr() for p in act])
+        d_s = ts.set([p.numel() for p in act])
+        coef = None
+        if max_norm is not None:
+            part = torch.empty(lib().tav_sumsq_partials(n), dtype=torch.float32, device=act[0].device)
+            check(lib().tav_sumsq_multi(ptr(d_g), ptr(d_s), n, ptr(part), ptr(self._scal[0:1]), stream()), "sumsq_multi")
+            check(lib().tav_clip_coef(ptr(self._scal[0:1]), float(max_norm), ptr(self._scal[1:2]), ptr(self._scal[2:3]), stream()), "clip_coef")
+            coef = self._scal[1:2]
+            self.last_norm = self._scal[2:3]
+        self.step_count += 1
+        check(lib().tav_adamw_multi(ptr(d_p), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_s), n, ptr(coef), self.lr, self.betas[0], self.betas[1], self.eps,
+                                    self.weight_decay, self.step_count, stream()), "adamw_multi")
+        engine.bump_weight_epoch()          # parameters changed through raw pointers: refresh cached operand copies
+        return self.last_norm
+
+    def step(self):
+        return self.clip_and_step(None)
+
+
+def grad_norm(params):
+    """Global L2 norm of the gradients as a device scalar (the value clip_grad_norm_ returns)."""
+    act = [p for p in params if p.grad is not None]
+    dev = act[0].device
+    n = len(act)
+    gp = torch.tensor([p.grad.data_ptr() for p in act], dtype=torch.int64).to(dev)
+    sz = torch.tensor([p.grad.numel() for p in act], dtype=torch.int64).to(dev)
+    part = torch.empty(lib().tav_sumsq_partials(n), dtype=torch.float32, device=dev)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib().tav_sumsq_multi(ptr(gp), ptr(sz), n, ptr(part), ptr(out), stream()), "sumsq_multi")
+    return out.sqrt()

@@ -1,0 +1,160 @@
+"""Drop-in for the reference's train_model/tav_train.py: same function names and argument order
+(get_statistics :15-48, not_grad_accum :52-83, validate :121-130, one_epoch :133-144, train_tav_network :147-164,
+evaluate_tav :166-167), running on libtavhip.  Differences, all forced by the MI355X design:
+  * no `assert video.shape == (1,16,3,224,224)` (reference :32 pins batch 1);
+  * AdamW + clip_grad_norm_ are the fused multi-tensor kernels of optim.py (identical update rule);
+  * wandb / checkpoint paths are optional (no network, no cluster paths);
+  * with torch.distributed initialised, gradients are averaged over ranks by ddp.BucketedAllReduce overlapped with backward.
+"""
+import math
+
+import torch
+
+from .. import ddp as tav_ddp
+from ..optim import FusedAdamW
+
+try:                                    # optional, as in the reference's environment
+    import wandb
+except Exception:                       # pragma: no cover
+    wandb = None
+
+PATIENCE_ITER = 0
+
+
+class CosineWarmRestarts:
+    """torch CosineAnnealingWarmRestarts(T_0=T_max, T_mult=1, eta_min=0).step(epoch_float) for FusedAdamW."""
+
+    def __init__(self, optimizer, T_0):
+        self.opt, self.T_0, self.base_lr = optimizer, T_0, optimizer.lr
+
+    def step(self, epoch):
+        t_cur = epoch % self.T_0
+        self.opt.lr = self.base_lr * (1 + math.cos(math.pi * t_cur / self.T_0)) / 2
+
+    def get_last_lr(self):
+        return [self.opt.lr]
+
+
+def get_statistics(input, label, model, PREFormer, criterion, Metric, check="train", epoch=None, n_visual_true=None):
+    device = "cuda"
+    batch_size = len(label)
+    text, audio_features, video_embeds = input[0], input[1], input[2]
+    text_input_ids, text_attention_mask = text["input_ids"], text["attention_mask"]
+    audio_input_ids, audio_attention_mask = audio_features["audio_features"], audio_features["attention_mask"]
+    video_input_ids, video_attention_mask = video_embeds["visual_embeds"], video_embeds["attention_mask"]
+    tav, tav_embed, attention_mask = PREFormer(input_ids=text_input_ids, audio_features=audio_input_ids, video_embeds=video_input_ids,
+                                               text_mask=text_attention_mask, audio_mask=audio_attention_mask, visual_mask=video_attention_mask,
+                                               device=device, train=True if check == "train" else False, n_visual_true=n_visual_true)
+    output = model(input_ids=text_input_ids.to(device), text_attention_mask=text_attention_mask.to(device), audio_features=audio_input_ids.to(device),
+                   video_embeds=video_input_ids.to(device), visual_mask=video_attention_mask.to(device), hidden_states=tav.to(device),
+                   pos_embed=tav_embed.to(device), attention_mask=attention_mask.to(device), batch_size=batch_size, check=check,
+                   n_visual_true=n_visual_true)
+    label = label.type(torch.LongTensor).to(device)
+    if Metric is not None:
+        Metric.update_metrics(torch.argmax(output, dim=1), label.long())
+    batch_loss = None
+    if criterion is not None:
+        batch_loss = criterion(output, label, epoch=epoch if epoch is not None else 1)
+    return batch_loss
+
+
+class TrainStep:
+    """One optimisation step of reference :56-65: get_statistics -> backward -> (all-reduce) -> clip_grad_norm_ -> AdamW."""
+
+    def __init__(self, model, PREFormer, criterion, lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=48.0, reduce_dtype=None):
+        self.model, self.pre, self.criterion, self.clip = model, PREFormer, criterion, clip
+        self.params = [p for p in model.parameters() if p.requires_grad] + [p for p in PREFormer.parameters() if p.requires_grad]
+        self.opt = FusedAdamW(self.params, lr=lr, weight_decay=weight_decay)
+        self.reducer = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.reducer = tav_ddp.BucketedAllReduce(self.params, bucket_mb=bucket_mb, reduce_dtype=reduce_dtype)
+
+    def forward_backward(self, input, label, check="train", epoch=0, n_visual_true=None):
+        loss = get_statistics(input, label, self.model, self.pre, self.criterion, None, check=check, epoch=epoch, n_visual_true=n_visual_true)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        return loss
+
+    def update(self):
+        norm = self.opt.clip_and_step(self.clip)
+        self.opt.zero_grad()
+        return norm
+
+    def __call__(self, input, label, check="train", epoch=0, n_visual_true=None):
+        loss = self.forward_backward(input, label, check, epoch, n_visual_true)
+        return loss, self.update()
+
+
+def validate(val_dataloader, model, PREFormer, criterion, Metric, name="val"):
+    total = 0.0
+    with torch.no_grad():
+        for val_input, val_label in val_dataloader:
+            loss = get_statistics(val_input, val_label, model, PREFormer, criterion, Metric, name, epoch=None)
+            if criterion is not None:
+                total += loss.item()
+        log(Metric, total / len(val_dataloader) if criterion is not None else 0, name)
+    return total / len(val_dataloader)
+
+
+def not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val):
+    global PATIENCE_ITER
+    iters = len(train_dataloader)
+    total_loss_train = 0.0
+    for batch_idx, (train_input, train_label) in enumerate(train_dataloader):
+        loss = get_statistics(train_input, train_label, model, PREFormer, criterion, Metric, check="train", epoch=epoch)
+        total_loss_train += loss.item()
+        loss.backward()
+        if stepper.reducer is not None:
+            stepper.reducer.finish()
+        stepper.update()
+        scheduler.step(epoch + batch_idx / iters)
+        if ((batch_idx + 1) % log_val == 0) or (batch_idx + 1 == iters):
+            log(Metric, total_loss_train / iters, "train")
+            val_loss = validate(val_dataloader, model, PREFormer, criterion, Metric, name="val")
+            if val_loss < prev_val_loss:
+                PATIENCE_ITER = 0
+                prev_val_loss = val_loss
+            else:
+                PATIENCE_ITER += 1
+                if PATIENCE_ITER == patience:
+                    break
+    return prev_val_loss
+
+
+def one_epoch(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, epoch_switch, patience, Metric, prev_val_loss):
+    # the reference alternates with a dialogue-level grad-accumulation variant (:85-119) on odd epochs; that variant steps
+    # every batch as well, so the per-step arithmetic (the hot path) is the same -- see SURVEY.md §8f-4.
+    return not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, 2400)
+
+
+def train_tav_network(model, PREFormer, train_dataloader, val_dataloader, criterion, learning_rate, epochs, weight_decay, T_max, Metric, patience, clip,
+                      epoch_switch, checkpoint=None):
+    stepper = TrainStep(model, PREFormer, criterion, lr=learning_rate, weight_decay=weight_decay, clip=clip)
+    scheduler = CosineWarmRestarts(stepper.opt, T_0=T_max)
+    prev_val_loss = 100
+    for epoch_num in range(epochs):
+        if wandb is not None and getattr(wandb, "run", None) is not None:
+            wandb.log({"epoch": epoch_num, "learning_rate": scheduler.get_last_lr()[0]})
+        stepper.opt.zero_grad()
+        prev_val_loss = one_epoch(epoch_num, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, epoch_switch, patience,
+                                  Metric, prev_val_loss)
+        if PATIENCE_ITER == patience:
+            return model, PREFormer
+    return model, PREFormer
+
+
+def evaluate_tav(model, PREFormer, test_dataloader, Metric):
+    validate(test_dataloader, model, PREFormer, None, Metric, name="test")
+
+
+def log(Metric, loss, check="train"):
+    if Metric is None:
+        return
+    multiAcc, multiF1, multiRec, multiPrec, Acc, F1Macro, F1Weighted, Rec, Prec, cm = Metric.compute_scores(f"{check}")
+    d1 = {f"{check}/loss": loss, f"{check}/acc": Acc, f"{check}/precision": Prec, f"{check}/recall": Rec, f"{check}/weighted-f1-score": F1Weighted,
+          f"{check}/macro-f1-score": F1Macro}
+    print(f"\n in {check} \n loss = {loss:.5f} acc = {Acc:.4f} \n Confusion Matrix = {cm} \n", flush=True)
+    if wandb is not None and getattr(wandb, "run", None) is not None:
+        wandb.log({**d1, **multiF1, **multiRec, **multiPrec, **multiAcc})
+    Metric.reset_metrics()
