@@ -70,6 +70,9 @@ typedef struct tav_gemm_tn_args {
     const void* A; const void* B;
     float* slabs;           /* workspace, nsplit*N1*N2 f32 */
     float* out;             /* [N1][N2] f32 */
+    float* dbias;           /* optional [N1] f32: (+)= scale * sum_{z,t} A[z][t][n1] -- the bias gradient, fused (the dY tiles
+                               are already in LDS); needs bias_partials = workspace nsplit*N1 f32 */
+    float* bias_partials;
     int64_t N1, N2;
     int64_t lda, ldb;
     int64_t rows_per_batch, nbatch;

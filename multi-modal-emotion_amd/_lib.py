@@ -28,7 +28,7 @@ class GemmNTArgs(C.Structure):
 
 
 class GemmTNArgs(C.Structure):
-    _fields_ = [("A", vp), ("B", vp), ("slabs", vp), ("out", vp),
+    _fields_ = [("A", vp), ("B", vp), ("slabs", vp), ("out", vp), ("dbias", vp), ("bias_partials", vp),
                 ("N1", i64), ("N2", i64), ("lda", i64), ("ldb", i64), ("rows_per_batch", i64), ("nbatch", i64),
                 ("a_zb", i64), ("b_zb", i64), ("chunk_rows", i32), ("nsplit", i32), ("perm_inner", i32), ("perm_outer", i32),
                 ("dtype", i32), ("accumulate", i32), ("scale", f32)]

@@ -61,20 +61,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     const char* Ab = p.A + (zb * p.a_zb + zg * p.a_zg) * ES;
     const char* Bb = p.B + (zb * p.b_zb + zg * p.b_zg) * ES;
 
-    // staging: thread -> (row r0 + 32*pass, chunk c)
-    const int c = tid & 7, r0 = tid >> 3;
+    // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction fills 64 consecutive 16-B slots = 8 rows x 8 chunk
+    // slots of the image; the LDS side is linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE
+    // chunk each lane fetches.  Wave w stages rows 32w..32w+31 of both operand tiles: 8 instructions per K-tile per wave.
+    const int lr = lane >> 3, lc = lane & 7;
     const char* ga[4];
     const char* gb[4];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        int ra = m0 + r0 + 32 * ps; ra = ra < p.M ? ra : p.M - 1;
-        int rb = n0 + r0 + 32 * ps; rb = rb < p.N ? rb : p.N - 1;
-        ga[ps] = Ab + (long)ra * p.lda * ES + c * 16;
-        gb[ps] = Bb + (long)rb * p.ldb * ES + c * 16;
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 32 + j * 8 + lr;
+        const int src_chunk = swz(r, lc);               // slot lc of row r holds chunk lc ^ f(r)
+        int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
+        int rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
+        ga[j] = Ab + (long)ra * p.lda * ES + src_chunk * 16;
+        gb[j] = Bb + (long)rb * p.ldb * ES + src_chunk * 16;
     }
-    int lds_w[4];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto stage = [&](int kt, int buf) {
+        const long ko = (long)kt * 128;
+        char* dA = sA + buf * TILE_BYTES + wave * 32 * 128;
+        char* dB = sB + buf * TILE_BYTES + wave * 32 * 128;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) { const int r = r0 + 32 * ps; lds_w[ps] = r * 128 + swz(r, c) * 16; }
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void*)(ga[j] + ko), (lds_void*)(dA + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gb[j] + ko), (lds_void*)(dB + j * 1024), 16, 0, 0);
+        }
+    };
 
     f32x4 acc[4][4];  // [tn][tm]
 #pragma unroll
@@ -83,38 +96,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / 128;
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define TAV_GLOAD(KT)                                                            \
-    do {                                                                         \
-        const long ko = (long)(KT) * 128;                                        \
-        ra0 = *reinterpret_cast<const uint4*>(ga[0] + ko); ra1 = *reinterpret_cast<const uint4*>(ga[1] + ko); \
-        ra2 = *reinterpret_cast<const uint4*>(ga[2] + ko); ra3 = *reinterpret_cast<const uint4*>(ga[3] + ko); \
-        rb0 = *reinterpret_cast<const uint4*>(gb[0] + ko); rb1 = *reinterpret_cast<const uint4*>(gb[1] + ko); \
-        rb2 = *reinterpret_cast<const uint4*>(gb[2] + ko); rb3 = *reinterpret_cast<const uint4*>(gb[3] + ko); \
-    } while (0)
-#define TAV_LSTORE(BUF)                                                          \
-    do {                                                                         \
-        char* nA = sA + (BUF) * TILE_BYTES; char* nB = sB + (BUF) * TILE_BYTES;  \
-        *reinterpret_cast<uint4*>(nA + lds_w[0]) = ra0; *reinterpret_cast<uint4*>(nA + lds_w[1]) = ra1; \
-        *reinterpret_cast<uint4*>(nA + lds_w[2]) = ra2; *reinterpret_cast<uint4*>(nA + lds_w[3]) = ra3; \
-        *reinterpret_cast<uint4*>(nB + lds_w[0]) = rb0; *reinterpret_cast<uint4*>(nB + lds_w[1]) = rb1; \
-        *reinterpret_cast<uint4*>(nB + lds_w[2]) = rb2; *reinterpret_cast<uint4*>(nB + lds_w[3]) = rb3; \
-    } while (0)
-    TAV_GLOAD(0);
-    TAV_LSTORE(0);
-    __syncthreads();
-
-    // fragment read offsets (row part); chunk part depends on the k-step
     int row_a[4], row_b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { row_a[t] = wm * 64 + t * 16 + i; row_b[t] = wn * 64 + t * 16 + i; }
 
+    stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        // prefetch the next K-tile into registers (the last iteration re-reads its own tile: harmless, keeps the
-        // loads unconditional so the staging registers never go through scratch)
-        const int ktn = kt + 1 < nk ? kt + 1 : kt;
-        TAV_GLOAD(ktn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile kt has landed ...
+        __syncthreads();                                    // ... and everybody's; buffer cur^1 is no longer being read
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);            // overlaps the MFMAs below
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
 #pragma unroll
@@ -130,11 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) mma16<T>(fb[tn], fa[tm], acc[tn][tm]);
         }
-        TAV_LSTORE(cur ^ 1);
-        __syncthreads();
     }
-#undef TAV_GLOAD
-#undef TAV_LSTORE
 
     // epilogue: lane holds C[m = .. + i][n = .. + 4g + r], r = 0..3
     const long coff = zb * p.c_zb + zg * p.c_zg;
@@ -169,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmTN {
     const char* A; const char* B; float* S;   // S: slabs [nsplit][N1][N2] fp32
+    float* bias_part;       // optional [nsplit][N1]: column sums of A (the bias gradient), written by the t2 == 0 tiles
     int N1, N2;
     long lda, ldb;          // row strides (elements) of the token-major operands
     int rows_per_batch;     // T: tokens per batch entry (reduction axis = nbatch * T)
@@ -219,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_part != nullptr && t2 == 0;
+    float bsum = 0.f;       // column (tid & 127) of the dY tile, rows (tid >> 7)*32 .. +31 of every K-tile
 
     const int nk = (row_end - row_begin + KT - 1) / KT;
     uint4 ra_[NPASS], rb_[NPASS];
@@ -260,10 +250,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
         }
+        if (do_bias) {
+            const T* colp = reinterpret_cast<const T*>(cA + (tid >> 7) * 32 * PITCH) + (tid & 127);
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) bsum += ET<T>::ld(reinterpret_cast<const T*>(reinterpret_cast<const char*>(colp) + r * PITCH));
+        }
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
 
+    if (do_bias) {          // block-uniform branch; the K loop ended with a barrier, so the staging LDS is free
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 128 && n1_0 + tid < p.N1) p.bias_part[(long)split * p.N1 + n1_0 + tid] = red[tid] + red[128 + tid];
+    }
     float* S = p.S + (long)split * p.N1 * p.N2;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -299,6 +300,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ S, float* __restr
             out[o] = accumulate ? out[o] + v[e] : v[e];
         }
     }
+}
+
+__global__ void bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nsplit, int N1, int accumulate, float scale) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N1) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(long)k * N1 + n];
+    s *= scale;
+    out[n] = accumulate ? out[n] + s : s;
 }
 
 // column sums (bias gradients): out[n] (+)= sum_m X[m][n], two deterministic stages.
@@ -384,6 +394,8 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     if (a->chunk_rows <= 0 || a->chunk_rows % 64) return TAV_ERR_SHAPE;
     GemmTN p;
     p.A = (const char*)a->A; p.B = (const char*)a->B; p.S = a->slabs;
+    p.bias_part = a->dbias ? a->bias_partials : nullptr;
+    if (a->dbias && !a->bias_partials) return TAV_ERR_NULL;
     p.N1 = (int)a->N1; p.N2 = (int)a->N2; p.lda = a->lda; p.ldb = a->ldb;
     p.rows_per_batch = (int)a->rows_per_batch; p.a_zb = a->a_zb; p.b_zb = a->b_zb;
     p.chunk_rows = a->chunk_rows;
@@ -407,6 +419,9 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     const long nthreads = (n_elems + 3) / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a->slabs, a->out, nsplit,
                        n_elems, p.N2, inner, outer, a->accumulate, a->scale == 0.f ? 1.f : a->scale);
+    if (a->dbias)
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)((p.N1 + 255) / 256)), dim3(256), 0, stream, a->bias_partials, a->dbias, nsplit, p.N1,
+                           a->accumulate, a->scale == 0.f ? 1.f : a->scale);
     return (int)hipGetLastError();
 }
 

@@ -190,11 +190,9 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
         # FFN
-        dW2 = ops.gemm_tn(dy2_lp, h)
-        dB2 = ops.colsum(dy2_lp)
+        dW2, dB2 = ops.gemm_tn(dy2_lp, h, want_bias=True)
         du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
-        dW1 = ops.gemm_tn(du, c)
-        dB1 = ops.colsum(du)
+        dW1, dB1 = ops.gemm_tn(du, c, want_bias=True)
         if spec.pre_ln:
             dc = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
@@ -203,13 +201,11 @@ class EncoderLayerFn(torch.autograd.Function):
             g1 = ops.gemm_nt(du, w1_t, resid=dy2, out_dtype=torch.float32)
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
         # attention
-        dWo = ops.gemm_tn(dy1_lp, o)
-        dBo = ops.colsum(dy1_lp)
+        dWo, dBo = ops.gemm_tn(dy1_lp, o, want_bias=True)
         do = ops.gemm_nt(dy1_lp, wo_t)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        dWqkv = ops.gemm_tn(dqkv, a)
-        dBqkv = ops.colsum(dqkv)
+        dWqkv, dBqkv = ops.gemm_tn(dqkv, a, want_bias=True)
         if spec.pre_ln:
             da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
             g0, _, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=False)
@@ -249,8 +245,14 @@ class LinearFn(torch.autograd.Function):
         _, w_t = ctx.ectx.cache.linear(w)
         gy = _c(gy)
         gy_lp = gy if gy.dtype == pol.lp else _to_lp(pol, gy)
-        dW = ops.gemm_tn(gy_lp, x_lp) if ctx.needs_input_grad[2] else None
-        dB = ops.colsum(gy_lp) if (b is not None and ctx.needs_input_grad[3]) else None
+        dW = dB = None
+        if ctx.needs_input_grad[2]:
+            if b is not None and ctx.needs_input_grad[3]:
+                dW, dB = ops.gemm_tn(gy_lp, x_lp, want_bias=True)
+            else:
+                dW = ops.gemm_tn(gy_lp, x_lp)
+        elif b is not None and ctx.needs_input_grad[3]:
+            dB = ops.colsum(gy_lp)
         dx = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = ops.gemm_nt(gy_lp, w_t, out_dtype=torch.float32 if ctx.in_f32 else pol.lp)

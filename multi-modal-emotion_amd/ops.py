@@ -87,8 +87,9 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
 
 
 def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb=None, rows_per_batch=None, nbatch=1,
-            a_zb=0, b_zb=0, perm_inner=0, perm_outer=0, scale=1.0, out_shape=None):
-    """out[n1][perm(n2)] (+)= sum_tokens A[t][n1] * B[t][n2]  (weight gradient)."""
+            a_zb=0, b_zb=0, perm_inner=0, perm_outer=0, scale=1.0, out_shape=None, want_bias=False):
+    """out[n1][perm(n2)] (+)= sum_tokens A[t][n1] * B[t][n2]  (weight gradient).  want_bias: also return
+    dbias[n1] = sum_tokens A[t][n1] computed inside the same kernel."""
     if N1 is None:
         N1, N2 = a.shape[-1], b.shape[-1]
         rows_per_batch = a.shape[-2]
@@ -104,9 +105,14 @@ def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb
     g.rows_per_batch, g.nbatch, g.a_zb, g.b_zb = rows_per_batch, nbatch, a_zb, b_zb
     g.chunk_rows, g.nsplit, g.perm_inner, g.perm_outer = cr.value, ns.value, perm_inner, perm_outer
     g.dtype, g.accumulate, g.scale = dt(a), int(accumulate), scale
+    dbias = None
+    if want_bias:
+        dbias = torch.empty(N1, dtype=torch.float32, device=a.device)
+        bpart = workspace("tn_bias", ns.value * N1, a.device)
+        g.dbias, g.bias_partials = ptr(dbias), ptr(bpart)
     assert a.dtype == b.dtype
     check(lib().tav_gemm_tn(C.byref(g), stream()), "gemm_tn")
-    return out
+    return (out, dbias) if want_bias else out
 
 
 def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):

@@ -69,9 +69,10 @@ def check_gemm_nt_gelu_bwd(dtype, M=200, N=384, K=256):
 def check_gemm_tn(dtype, M=1000, N1=256, N2=384, nbatch=1):
     a = _rnd(nbatch * M, N1, dtype=dtype, seed=8)
     b = _rnd(nbatch * M, N2, dtype=dtype, seed=9)
-    out = ops.gemm_tn(a, b, N1=N1, N2=N2, lda=N1, ldb=N2, rows_per_batch=M, nbatch=nbatch, a_zb=M * N1, b_zb=M * N2)
+    out, dbias = ops.gemm_tn(a, b, N1=N1, N2=N2, lda=N1, ldb=N2, rows_per_batch=M, nbatch=nbatch, a_zb=M * N1, b_zb=M * N2, want_bias=True)
     ref = a.float().t() @ b.float()
-    return [_res(f"gemm_tn[{dtype},M{M},N1{N1},N2{N2},nb{nbatch}]", out, ref, 2e-3 if dtype == torch.bfloat16 else 2e-5)]
+    return [_res(f"gemm_tn[{dtype},M{M},N1{N1},N2{N2},nb{nbatch}]", out, ref, 2e-3 if dtype == torch.bfloat16 else 2e-5),
+            _res("gemm_tn.dbias", dbias, a.float().sum(0), 1e-5)]
 
 
 def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
