@@ -118,6 +118,24 @@ template <> TAV_DEV uint4 acc_to_kfrag<float>(const f32x4* t) {
                       __float_as_uint(t[0][3]));
 }
 
+// ---- LDS-DMA (global -> LDS without VGPRs) ----------------------------------------------------------------------
+// 32-bit LDS byte address of a __shared__ pointer
+TAV_DEV unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+// One wave instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_base + 16*l).
+// lds_base must be wave-uniform.  Issued from inline asm on purpose: hipcc would otherwise treat the DMA as a pending LDS
+// write and put `s_waitcnt vmcnt(0)` in front of every following ds_read, serialising load and compute.  The caller
+// waits with wait_vmcnt0() + a barrier before any wave reads the staged bytes.
+TAV_DEV void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+TAV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- wave reductions ----------------------------------------------------------------------------
 TAV_DEV float wave_sum(float v) {
 #pragma unroll

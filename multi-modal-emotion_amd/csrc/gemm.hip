@@ -53,8 +53,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     const int g = lane >> 4, i = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
 
+    // tile order: XCD band (xcd_remap), then super-tiles of GROUP_M m-tiles walked m-fastest, so the ~64 workgroups an XCD
+    // runs at once cover an 8x8 patch: 8 A panels + 8 B panels (~3 MB at K = 768) stay inside its 4 MiB L2.
+    constexpr int GROUP_M = 8;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tm_idx = tile / p.tiles_n, tn_idx = tile - tm_idx * p.tiles_n;
+    const int gsz = GROUP_M * p.tiles_n;
+    const int first_m = (tile / gsz) * GROUP_M;
+    const int gm = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
+    const int rem = tile % gsz;
+    const int tm_idx = first_m + rem % gm, tn_idx = rem / gm;
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     const int z = blockIdx.y, zb = z / p.nzg, zg = z - zb * p.nzg;
 
@@ -76,16 +83,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         ga[j] = Ab + (long)ra * p.lda * ES + src_chunk * 16;
         gb[j] = Bb + (long)rb * p.ldb * ES + src_chunk * 16;
     }
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 32 * 128);
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 32 * 128);
     auto stage = [&](int kt, int buf) {
         const long ko = (long)kt * 128;
-        char* dA = sA + buf * TILE_BYTES + wave * 32 * 128;
-        char* dB = sB + buf * TILE_BYTES + wave * 32 * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_void*)(ga[j] + ko), (lds_void*)(dA + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(gb[j] + ko), (lds_void*)(dB + j * 1024), 16, 0, 0);
+            glds16(ga[j] + ko, ldsA + buf * TILE_BYTES + j * 1024);
+            glds16(gb[j] + ko, ldsB + buf * TILE_BYTES + j * 1024);
         }
     };
 
@@ -100,27 +105,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) { row_a[t] = wm * 64 + t * 16 + i; row_b[t] = wn * 64 + t * 16 + i; }
 
+    // per-lane LDS read offsets of the two k-steps (chunk 4s+g, swizzled), hoisted out of the loop
+    int off_a[2][4], off_b[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            off_a[s2][t] = row_a[t] * 128 + swz(row_a[t], 4 * s2 + g) * 16;
+            off_b[s2][t] = row_b[t] * 128 + swz(row_b[t], 4 * s2 + g) * 16;
+        }
+    uint4 fa0[4], fb0[4], fa1[4], fb1[4];      // two fragment sets: the reads of one k-step fly under the MFMAs of the other
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile kt has landed ...
+        wait_vmcnt0();                                      // this wave's DMA of tile kt has landed ...
         __syncthreads();                                    // ... and everybody's; buffer cur^1 is no longer being read
         if (kt + 1 < nk) stage(kt + 1, cur ^ 1);            // overlaps the MFMAs below
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 fa[4], fb[4];
+        for (int t = 0; t < 4; ++t) { fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]); fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]); }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = *reinterpret_cast<const uint4*>(cA + row_a[t] * 128 + swz(row_a[t], 4 * s + g) * 16);
-                fb[t] = *reinterpret_cast<const uint4*>(cB + row_b[t] * 128 + swz(row_b[t], 4 * s + g) * 16);
-            }
+        for (int t = 0; t < 4; ++t) { fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]); fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]); }
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm) mma16<T>(fb[tn], fa[tm], acc[tn][tm]);
-        }
+            for (int tm = 0; tm < 4; ++tm) mma16<T>(fb0[tn], fa0[tm], acc[tn][tm]);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
     }
 
     // epilogue: lane holds C[m = .. + i][n = .. + 4g + r], r = 0..3
