@@ -297,7 +297,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------------ optimiser
-constexpr int SUMSQ_BLOCKS = 32;
+constexpr int SUMSQ_BLOCKS = 96;
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const float* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float* __restrict__ partials) {
     __shared__ float red[256];
     const int t = blockIdx.y;
@@ -545,7 +545,7 @@ extern "C" int tav_adamw_multi(float* const* params, const float* const* grads, 
     if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes) return TAV_ERR_NULL;
     if (ntensors <= 0 || ntensors > 65535 || step <= 0) return TAV_ERR_SHAPE;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3(64, ntensors), dim3(256), 0, ST, params, grads, exp_avg, exp_avg_sq, sizes, clip_coef, lr, beta1, beta2, eps,
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(192, ntensors), dim3(256), 0, ST, params, grads, exp_avg, exp_avg_sq, sizes, clip_coef, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2);
     return tav_last_error();
 }

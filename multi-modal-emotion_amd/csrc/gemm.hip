@@ -180,20 +180,52 @@ struct GemmTN {
     int tiles_1, tiles_2;
 };
 
+// LDS image of one TN operand tile: [64 tokens][128 features] in natural order, 16-B chunks XOR-swizzled per row so the
+// token rows one half-wave touches in a single transposed read fall into different bank windows:
+//   bf16 (ds_read_b64_tr_b16, 8 rows x 32 B, 64 banks): chunk ^ ((row & 7) << 1)  -> 8 distinct 32-B windows of 256 B
+//   f32  (ds_read_b32, 2 rows x 64 B, 32 banks)       : chunk ^ (((row >> 2) & 1) << 2) -> the two rows 64 B apart
+// The image is linear per wave instruction, so it is filled by LDS-DMA with the swizzle applied to the source chunk.
+template <typename T> struct TNTile {
+    static constexpr int ES = ET<T>::ES, ROWB = 128 * ES, CPR = ROWB / 16;
+    static TAV_DEV int sw(int row, int chunk) { return ES == 2 ? (chunk ^ ((row & 7) << 1)) : (chunk ^ (((row >> 2) & 1) << 2)); }
+};
+template <typename T> TAV_DEV uint4 tn_frag(const char* tile, int krow0, int col0, int lane);
+template <> TAV_DEV uint4 tn_frag<bf16>(const char* tile, int krow0, int col0, int lane) {
+    using TT = TNTile<bf16>;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = krow0 + 4 * g + q, r1 = r0 + 16;
+    const int cb = (col0 + 4 * p) * 2;                         // byte column of this lane's 4 elements
+    const char* a0 = tile + r0 * TT::ROWB + (TT::sw(r0, cb >> 4) << 4) + (cb & 15);
+    const char* a1 = tile + r1 * TT::ROWB + (TT::sw(r1, cb >> 4) << 4) + (cb & 15);
+    const uint2 lo = lds_read_tr16(a0), hi = lds_read_tr16(a1);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+template <> TAV_DEV uint4 tn_frag<float>(const char* tile, int krow0, int col0, int lane) {
+    using TT = TNTile<float>;
+    const int g = lane >> 4, i = lane & 15;
+    const int cb = (col0 + i) * 4;
+    uint4 r;
+    uint32_t* rr = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = krow0 + 4 * g + t;
+        rr[t] = *reinterpret_cast<const uint32_t*>(tile + row * TT::ROWB + (TT::sw(row, cb >> 4) << 4) + (cb & 15));
+    }
+    return r;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+    using TT = TNTile<T>;
     constexpr int ES = ET<T>::ES, PK = ET<T>::PK, KSTEP = ET<T>::KSTEP;
-    constexpr int BT = 128;                       // tile edge (elements) on both output axes
-    constexpr int ROWB = BT * ES;                 // bytes per natural row
-    constexpr int PITCH = ROWB + (ES == 2 ? 32 : 16);   // bf16: +8 banks/row (tr_b16 reads of 8 rows hit 64 distinct banks); f32: 4 rows = +16 banks (b32 reads)
-    constexpr int KT = 64;                        // tokens per K-tile
-    constexpr int TILE_BYTES = KT * PITCH;
-    constexpr int CPR = ROWB / 16;                // chunks per row (16 or 32)
-    constexpr int RSTEP = 256 / CPR;              // rows covered per pass (16 or 8)
-    constexpr int NPASS = KT / RSTEP;             // 4 or 8
+    constexpr int BT = 128, KT = 64;
+    constexpr int ROWB = TT::ROWB, CPR = TT::CPR;           // 256 B / 16 chunks (bf16), 512 B / 32 chunks (f32)
+    constexpr int TILE_BYTES = KT * ROWB;
+    constexpr int RPI = 64 / CPR;                           // token rows per wave instruction (4 / 2)
+    constexpr int NINST = KT / (4 * RPI);                   // DMA instructions per wave per operand per K-tile (4 / 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                    // [2][KT][PITCH]  dY  (n1 along the row)
-    char* sB = smem + 2 * TILE_BYTES;   // [2][KT][PITCH]  X   (n2 along the row)
+    char* sA = smem;                    // [2][KT][ROWB]  dY  (n1 along the row)
+    char* sB = smem + 2 * TILE_BYTES;   // [2][KT][ROWB]  X   (n2 along the row)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -210,11 +242,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     const char* Ab = p.A + zb * p.a_zb * ES;
     const char* Bb = p.B + zb * p.b_zb * ES;
 
-    const int c = tid % CPR, r0 = tid / CPR;
-    const bool a_col_ok = (n1_0 + c * PK) < p.N1;
-    const bool b_col_ok = (n2_0 + c * PK) < p.N2;
-    const char* ga = Ab + (long)(n1_0 + c * PK) * ES;
-    const char* gb = Bb + (long)(n2_0 + c * PK) * ES;
+    // DMA geometry: wave w stages token rows [16w, 16w+16) of each K-tile; instruction j covers RPI rows; lane -> (row, slot)
+    const int lrow = lane / CPR, lslot = lane % CPR;
+    // Feature columns past N1/N2: the source chunk is clamped to chunk 0 (valid memory); those outputs are never stored.
+    // Token rows past the split end would pollute the sums, so a ragged last K-tile is staged by ordinary loads with
+    // zero fill instead of DMA (block-uniform branch, at most once per workgroup).
+    const int a_cmax = (p.N1 - n1_0) * ES / 16, b_cmax = (p.N2 - n2_0) * ES / 16;   // valid chunks in this tile (may exceed CPR)
 
     f32x4 acc[4][4];  // [t1][t2]
 #pragma unroll
@@ -222,33 +255,47 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.bias_part != nullptr && t2 == 0;
-    float bsum = 0.f;       // column (tid & 127) of the dY tile, rows (tid >> 7)*32 .. +31 of every K-tile
+    float bsum = 0.f;
 
-    const int nk = (row_end - row_begin + KT - 1) / KT;
-    uint4 ra_[NPASS], rb_[NPASS];
-    auto gload = [&](int kt) {
+    const int nrows = row_end - row_begin;
+    const int nk = (nrows + KT - 1) / KT;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 16 * ROWB);
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 16 * ROWB);
+    auto stage = [&](int kt, int buf) {
+        const int base_row = row_begin + kt * KT + wave * 16;
+        const bool full = (kt + 1) * KT <= nrows;               // block-uniform
+        if (full) {
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int row = row_begin + kt * KT + r0 + ps * RSTEP;
-            const bool ok = row < row_end;
-            ra_[ps] = (ok && a_col_ok) ? *reinterpret_cast<const uint4*>(ga + (long)row * p.lda * ES) : make_uint4(0, 0, 0, 0);
-            rb_[ps] = (ok && b_col_ok) ? *reinterpret_cast<const uint4*>(gb + (long)row * p.ldb * ES) : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < NINST; ++j) {
+                const int r = j * RPI + lrow;                      // row inside this wave's 16
+                const int trow = wave * 16 + r;                    // row inside the K-tile
+                int ca = TT::sw(trow, lslot); ca = ca < a_cmax ? ca : 0;
+                int cb = TT::sw(trow, lslot); cb = cb < b_cmax ? cb : 0;
+                glds16(Ab + ((long)(base_row + r) * p.lda + n1_0) * ES + ca * 16, ldsA + buf * TILE_BYTES + j * 1024);
+                glds16(Bb + ((long)(base_row + r) * p.ldb + n2_0) * ES + cb * 16, ldsB + buf * TILE_BYTES + j * 1024);
+            }
+        } else {                                                    // ragged last K-tile: ordinary loads, zero fill
+#pragma unroll 1
+            for (int j = 0; j < NINST; ++j) {
+                const int r = j * RPI + lrow;
+                const int trow = wave * 16 + r;
+                const int ca = TT::sw(trow, lslot), cb = TT::sw(trow, lslot);
+                const bool ok = (kt * KT + trow) < nrows;
+                uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+                if (ok && ca < a_cmax) va = *reinterpret_cast<const uint4*>(Ab + ((long)(base_row + r) * p.lda + n1_0) * ES + ca * 16);
+                if (ok && cb < b_cmax) vb = *reinterpret_cast<const uint4*>(Bb + ((long)(base_row + r) * p.ldb + n2_0) * ES + cb * 16);
+                *reinterpret_cast<uint4*>(sA + buf * TILE_BYTES + trow * ROWB + lslot * 16) = va;
+                *reinterpret_cast<uint4*>(sB + buf * TILE_BYTES + trow * ROWB + lslot * 16) = vb;
+            }
         }
     };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int off = (r0 + ps * RSTEP) * PITCH + c * 16;
-            *reinterpret_cast<uint4*>(sA + buf * TILE_BYTES + off) = ra_[ps];
-            *reinterpret_cast<uint4*>(sB + buf * TILE_BYTES + off) = rb_[ps];
-        }
-    };
-    if (nk > 0) { gload(0); lstore(0); }
-    __syncthreads();
 
+    if (nk > 0) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        wait_vmcnt0();
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
 #pragma unroll
@@ -256,24 +303,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
             uint4 f1[4], f2[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                f1[t] = frag_kstrided<T>(cA, PITCH, s * KSTEP, w1 * 64 + t * 16, lane);
-                f2[t] = frag_kstrided<T>(cB, PITCH, s * KSTEP, w2 * 64 + t * 16, lane);
+                f1[t] = tn_frag<T>(cA, s * KSTEP, w1 * 64 + t * 16, lane);
+                f2[t] = tn_frag<T>(cB, s * KSTEP, w2 * 64 + t * 16, lane);
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
         }
-        if (do_bias) {
-            const T* colp = reinterpret_cast<const T*>(cA + (tid >> 7) * 32 * PITCH) + (tid & 127);
+        if (do_bias) {      // column (tid & 127) of the dY tile, token rows (tid >> 7)*32 .. +31
+            const int col = tid & 127, cbyte = col * ES;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) bsum += ET<T>::ld(reinterpret_cast<const T*>(reinterpret_cast<const char*>(colp) + r * PITCH));
+            for (int r = 0; r < 32; ++r) {
+                const int row = (tid >> 7) * 32 + r;
+                bsum += ET<T>::ld(reinterpret_cast<const T*>(cA + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
+            }
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
     }
+    __syncthreads();
 
-    if (do_bias) {          // block-uniform branch; the K loop ended with a barrier, so the staging LDS is free
+    if (do_bias) {
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
@@ -419,10 +468,10 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     p.tiles_1 = (p.N1 + 127) / 128; p.tiles_2 = (p.N2 + 127) / 128;
     dim3 grid(p.tiles_1 * p.tiles_2, nsplit), block(256);
     if (a->dtype == TAV_BF16) {
-        const size_t lds = 4 * 64 * (256 + 32);
+        const size_t lds = 4 * 64 * 256;
         hipLaunchKernelGGL((gemm_tn_kernel<bf16>), grid, block, lds, stream, p);
     } else {
-        const size_t lds = 4 * 64 * (512 + 16);
+        const size_t lds = 4 * 64 * 512;
         hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, block, lds, stream, p);
     }
     int e = (int)hipGetLastError();

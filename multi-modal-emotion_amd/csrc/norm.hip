@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 
 static inline int ln_blocks(long rows) {
     long b = (rows + 15) / 16;      // >= 4 rows per wave so the per-lane dgamma/dbeta partials amortise
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 
 // ------------------------------------------------------------------------------------------------ group norm over time
