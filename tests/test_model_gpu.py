@@ -1,0 +1,173 @@
+"""-m gpu: the product path (libtavhip through the reference's nn.Module interface) against the CPU oracle and the
+committed golden vectors, plus size-independent properties at the benchmark's full input sizes.
+Tolerances (BASELINE.json north_star): 1e-3 relative for the fp32 policy, 1e-2 for bf16 -- logits, loss, global grad-norm."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import closed_form as cf
+import tav_amd  # noqa: F401
+from oracle import tav_oracle as O
+from tav_amd import config as C
+from tav_amd import engine as E
+from tav_amd import runtime, synthetic
+from tav_amd.models.tav import PreFormer, TAVForMAE
+from tav_amd.optim import FusedAdamW, grad_norm
+from tav_amd.utils.TAVFormer import VideoMAEEncoder
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "tav_golden.npz"))
+ARGS = dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _run_product(pre, model, batch, labels, check="val"):
+    tav, emb, amask = pre(input_ids=batch["input_ids"], audio_features=batch["audio_features"], video_embeds=batch["video_embeds"],
+                          text_mask=batch["text_mask"], audio_mask=batch["audio_mask"], visual_mask=batch["visual_mask"], device="cuda", train=False)
+    logits = model(batch["input_ids"], batch["text_mask"], batch["audio_features"], batch["video_embeds"], batch["visual_mask"], tav, emb, amask,
+                   batch_size=len(labels), check=check)
+    loss = E.CrossEntropyFn.apply(logits, labels.long().cuda(), None)
+    return tav, emb, amask, logits, loss
+
+
+def _as_batch(tx, au, vi):
+    return dict(input_ids=tx["input_ids"], text_mask=tx["attention_mask"], audio_features=au["audio_features"], audio_mask=au["attention_mask"],
+                video_embeds=vi["visual_embeds"], visual_mask=vi["attention_mask"])
+
+
+@pytest.mark.parametrize("preset", ["A", "B"])
+def test_golden_closed_form_fp32(gpu, preset):
+    """Closed-form weights/inputs: product (fp32 policy) reproduces what the reference-side modules produced."""
+    cfg = C.preset(preset + "-tiny")
+    runtime.set_precision("fp32")
+    pre = cf.fill_module_(PreFormer(cfg)).cuda()
+    model = cf.fill_module_(TAVForMAE(ARGS, cfg)).cuda()
+    batch, labels = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=16, image=32, vocab=cfg["text"]["vocab"], pad_id=cfg["text"]["pad_id"], nkeep_fusion=4)
+    tav, emb, amask, logits, loss = _run_product(pre, model, batch, labels)
+    loss.backward()
+    assert rel(tav, GOLD[f"{preset}_pre_tav"]) < 1e-4
+    assert (emb.cpu().numpy() == GOLD[f"{preset}_pre_tav_embed"]).all()
+    assert rel(amask, GOLD[f"{preset}_pre_attention_mask"]) == 0.0
+    assert rel(logits, GOLD[f"{preset}_logits"]) < 1e-3
+    assert abs(loss.item() - GOLD[f"{preset}_loss"][0]) / GOLD[f"{preset}_loss"][0] < 1e-3
+    gn = grad_norm(list(pre.parameters()) + list(model.parameters())).item()
+    assert abs(gn - GOLD[f"{preset}_gradnorm"][0]) / GOLD[f"{preset}_gradnorm"][0] < 1e-3
+    assert rel(model.linear1.weight.grad[:, :16], GOLD[f"{preset}_grad_linear1"]) < 1e-3
+
+
+@pytest.mark.parametrize("S,mname", [(8, "none"), (37, "zeros"), (37, "refstyle")])
+def test_fusion_encoder_golden_fp32(gpu, S, mname):
+    runtime.set_precision("fp32")
+    enc = cf.fill_module_(VideoMAEEncoder(dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12), 2)).cuda()
+    x = (cf.tensor_for(f"fusion_x{S}", (2, S, 768), kind="bias") * 20).cuda().requires_grad_(True)
+    m = torch.zeros(2, 1, 1, S)
+    if mname == "refstyle":
+        m[..., : S // 4] = O.FP16_MIN
+        m[..., S // 4: S // 2] = 65505.0
+        m[0, ..., S // 2 - 1] = 1.0
+    y = enc(x, None if mname == "none" else m.cuda())
+    (y.square().mean()).backward() if False else None
+    assert rel(y, GOLD[f"fusion_S{S}_{mname}_y"]) < 1e-4
+
+
+@pytest.mark.parametrize("preset,policy,tol", [("B", "fp32", 1e-3), ("A", "fp32", 1e-3), ("B", "bf16", 1e-2), ("A", "bf16", 1e-2)])
+def test_parity_vs_oracle_random_weights(gpu, preset, policy, tol):
+    """Seeded random weights (BASELINE.md §3 protocol): logits, loss, global grad-norm and per-tensor gradients vs the oracle."""
+    cfg = C.preset(preset + "-tiny")
+    runtime.set_precision(policy)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=32, t_audio=16000, n_visual_true=8)
+    batch = _as_batch(tx, au, vi)
+    sdp = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+    sdm = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, lab.long())
+    o_loss.backward()
+    pre.cuda()
+    model.cuda()
+    _, _, _, logits, loss = _run_product(pre, model, batch, lab)
+    loss.backward()
+    assert rel(logits, o_logits) < tol
+    assert abs(loss.item() - o_loss.item()) / abs(o_loss.item()) < tol
+    o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in list(sdp.values()) + list(sdm.values()) if v.requires_grad and v.grad is not None)).item()
+    gn = grad_norm(list(pre.parameters()) + list(model.parameters())).item()
+    assert abs(gn - o_gn) / o_gn < tol
+    gmax = max(v.grad.abs().max().item() for v in list(sdp.values()) + list(sdm.values()) if getattr(v, "grad", None) is not None)
+    worst = 0.0
+    for mod, sdo in ((pre, sdp), (model, sdm)):
+        for k, p in mod.named_parameters():
+            og = sdo[k].grad
+            assert (p.grad is None) == (og is None), f"gradient presence differs for {k}"     # same set of trained parameters as the reference
+            if og is not None:
+                worst = max(worst, (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax))
+    assert worst < (3e-2 if policy == "bf16" else 1e-3), worst
+
+
+def test_full_size_properties_bf16(gpu):
+    """BASELINE-sized inputs (text 128, audio 80000, video 16x3x224x224, 104/1464 video tokens), preset B depth-reduced to fit the test budget:
+    (1) deterministic (bitwise) across runs, (2) utterances are independent: batch of 4 == two batches of 2 (what DP sharding relies on),
+    (3) permuting the batch permutes the logits."""
+    cfg = C.preset("B")
+    for k in ("text", "audio", "video", "fusion"):
+        cfg[k]["layers"] = 2
+    runtime.set_precision("bf16")
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    pre.cuda()
+    model.cuda()
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 4, device="cuda")
+    au["attention_mask"][:] = 1            # equal audio lengths so that padding does not couple the split batches
+    batch = _as_batch(tx, au, vi)
+
+    def fwd(sel):
+        b = {k: v[sel] for k, v in batch.items()}
+        with torch.no_grad():
+            return _run_product(pre, model, b, lab[sel])[3]
+
+    full = fwd(torch.arange(4))
+    again = fwd(torch.arange(4))
+    assert torch.equal(full, again)
+    halves = torch.cat([fwd(torch.tensor([0, 1])), fwd(torch.tensor([2, 3]))])
+    assert rel(halves, full) < 2e-3
+    perm = torch.tensor([2, 0, 3, 1])
+    assert rel(fwd(perm), full[perm]) < 2e-3
+    assert torch.isfinite(full).all()
+
+
+def test_dropout_train_mode(gpu):
+    cfg = C.preset("B-tiny")
+    runtime.set_precision("fp32")
+    pre, model = PreFormer(cfg).cuda(), TAVForMAE(ARGS, cfg).cuda()
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")
+    batch = _as_batch(tx, au, vi)
+    a = _run_product(pre, model, batch, lab, check="train")[3]
+    b = _run_product(pre, model, batch, lab, check="train")[3]
+    c = _run_product(pre, model, batch, lab, check="val")[3]
+    assert not torch.equal(a, b) and torch.isfinite(a).all() and torch.isfinite(c).all()      # fresh mask per call (models/tav.py:497-498)
+
+
+def test_fused_adamw_matches_torch(gpu):
+    torch.manual_seed(0)
+    shapes = [(768, 768), (3072,), (7, 3072), (5,), (50, 3, 10)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.AdamW(qs, lr=1e-3, weight_decay=1e-2)
+    opt = FusedAdamW(ps, lr=1e-3, weight_decay=1e-2)
+    for step in range(3):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p) * (3.0 if step == 1 else 0.1)
+            p.grad, q.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step()
+        n = opt.clip_and_step(1.0)
+        assert abs(n.item() - n_ref.item()) / n_ref.item() < 1e-5
+        for p, q in zip(ps, qs):
+            assert rel(p, q) < 1e-5
