@@ -24,7 +24,7 @@ class GemmNTArgs(C.Structure):
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("ld_pre", i64), ("ld_gelu_in", i64), ("ld_resid", i64),
                 ("nzb", i32), ("nzg", i32),
                 ("a_zb", i64), ("a_zg", i64), ("b_zb", i64), ("b_zg", i64), ("c_zb", i64), ("c_zg", i64), ("bias_zg", i64),
-                ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("alpha", f32)]
+                ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("alpha", f32), ("tile_m_hint", i32)]
 
 
 class GemmTNArgs(C.Structure):

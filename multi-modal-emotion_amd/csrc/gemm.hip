@@ -40,21 +40,23 @@ TAV_DEV int xcd_remap(int id, int total) {
     return base + k;
 }
 
-template <typename T, typename TO>
+// TM = 16-row MFMA tiles per wave along M (2, 3 or 4): the workgroup tile is (32*TM) x 128.  The host picks TM per launch so that
+// the tile count divides well over the 256 CUs (e.g. M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle
+// in the last round, 732 tiles of 96 rows do not) and small-M problems still produce enough workgroups.
+template <typename T, typename TO, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
-    constexpr int BM = 128, BN = 128;
-    constexpr int TILE_BYTES = BM * 128;  // one operand tile
+    constexpr int BM = 32 * TM, BN = 128;
+    constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes per K-tile image
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                    // [2][BM][128B]  activations (m)
-    char* sB = smem + 2 * TILE_BYTES;   // [2][BN][128B]  weights (n)
+    char* sA = smem;                  // [2][BM][128B]  activations (m)
+    char* sB = smem + 2 * TILE_A;     // [2][BN][128B]  weights (n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // tile order: XCD band (xcd_remap), then super-tiles of GROUP_M m-tiles walked m-fastest, so the ~64 workgroups an XCD
-    // runs at once cover an 8x8 patch: 8 A panels + 8 B panels (~3 MB at K = 768) stay inside its 4 MiB L2.
+    // tile order: XCD band (xcd_remap), then super-tiles of GROUP_M m-tiles walked m-fastest (L2 locality)
     constexpr int GROUP_M = 8;
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int gsz = GROUP_M * p.tiles_n;
@@ -70,71 +72,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 
     // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction fills 64 consecutive 16-B slots = 8 rows x 8 chunk
     // slots of the image; the LDS side is linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE
-    // chunk each lane fetches.  Wave w stages rows 32w..32w+31 of both operand tiles: 8 instructions per K-tile per wave.
+    // chunk each lane fetches.  Wave w stages rows [8*TM*w, +8*TM) of A and [32w, +32) of B.
     const int lr = lane >> 3, lc = lane & 7;
-    const char* ga[4];
+    const char* ga[TM];
     const char* gb[4];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int r = wave * 8 * TM + j * 8 + lr;
+        int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
+        ga[j] = Ab + (long)ra * p.lda * ES + swz(r, lc) * 16;     // slot lc of row r holds chunk lc ^ f(r)
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = wave * 32 + j * 8 + lr;
-        const int src_chunk = swz(r, lc);               // slot lc of row r holds chunk lc ^ f(r)
-        int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
         int rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
-        ga[j] = Ab + (long)ra * p.lda * ES + src_chunk * 16;
-        gb[j] = Bb + (long)rb * p.ldb * ES + src_chunk * 16;
+        gb[j] = Bb + (long)rb * p.ldb * ES + swz(r, lc) * 16;
     }
-    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 32 * 128);
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 8 * TM * 128);
     const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 32 * 128);
     auto stage = [&](int kt, int buf) {
         const long ko = (long)kt * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(ga[j] + ko, ldsA + buf * TILE_BYTES + j * 1024);
-            glds16(gb[j] + ko, ldsB + buf * TILE_BYTES + j * 1024);
-        }
+        for (int j = 0; j < TM; ++j) glds16(ga[j] + ko, ldsA + buf * TILE_A + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(gb[j] + ko, ldsB + buf * TILE_B + j * 1024);
     };
 
-    f32x4 acc[4][4];  // [tn][tm]
+    f32x4 acc[4][TM];  // [tn][tm]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / 128;
-    int row_a[4], row_b[4];
+    int off_a[2][TM], off_b[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { row_a[t] = wm * 64 + t * 16 + i; row_b[t] = wn * 64 + t * 16 + i; }
-
-    // per-lane LDS read offsets of the two k-steps (chunk 4s+g, swizzled), hoisted out of the loop
-    int off_a[2][4], off_b[2][4];
+    for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+        for (int t = 0; t < TM; ++t) { const int r = wm * 16 * TM + t * 16 + i; off_a[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            off_a[s2][t] = row_a[t] * 128 + swz(row_a[t], 4 * s2 + g) * 16;
-            off_b[s2][t] = row_b[t] * 128 + swz(row_b[t], 4 * s2 + g) * 16;
-        }
-    uint4 fa0[4], fb0[4], fa1[4], fb1[4];      // two fragment sets: the reads of one k-step fly under the MFMAs of the other
+        for (int t = 0; t < 4; ++t) { const int r = wn * 64 + t * 16 + i; off_b[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
+    }
+    uint4 fa0[TM], fb0[4], fa1[TM], fb1[4];
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         wait_vmcnt0();                                      // this wave's DMA of tile kt has landed ...
         __syncthreads();                                    // ... and everybody's; buffer cur^1 is no longer being read
         if (kt + 1 < nk) stage(kt + 1, cur ^ 1);            // overlaps the MFMAs below
-        const char* cA = sA + cur * TILE_BYTES;
-        const char* cB = sB + cur * TILE_BYTES;
+        const char* cA = sA + cur * TILE_A;
+        const char* cB = sB + cur * TILE_B;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]); fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]); }
+        for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]); fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]); }
+        for (int t = 0; t < 4; ++t) fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) mma16<T>(fb0[tn], fa0[tm], acc[tn][tm]);
+            for (int tm = 0; tm < TM; ++tm) mma16<T>(fb0[tn], fa0[tm], acc[tn][tm]);
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
+            for (int tm = 0; tm < TM; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
     }
 
     // epilogue: lane holds C[m = .. + i][n = .. + 4g + r], r = 0..3
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     const float* R = p.resid ? p.resid + coff : nullptr;
     const float* bias = p.bias ? p.bias + zg * p.bias_zg : nullptr;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int m = m0 + wm * 64 + tm * 16 + i;
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + wm * 16 * TM + tm * 16 + i;
         if (m >= p.M) continue;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
@@ -345,8 +348,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 // out[n1][perm(n2)] (+)= sum_s S[s][n1][n2];  perm(n2) = (n2 % inner) * outer + n2 / inner  (outer = 1: identity).
 // Used with inner = C_in, outer = kernel width to hand conv wgrads back in nn.Conv1d's [co][ci][k] order.
 __global__ void splitk_reduce_kernel(const float* __restrict__ S, float* __restrict__ out, int nsplit, long n_elems, int N2,
-                                     int inner, int outer, int accumulate, float scale) {
-    const long idx4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+                                     int inner, int outer, int accumulate, float scale, const float* __restrict__ bias_part,
+                                     float* __restrict__ dbias, int N1) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias && gid < N1) {          // the first N1 threads also finish the fused bias gradient (one launch fewer)
+        float b = 0.f;
+        for (int s = 0; s < nsplit; ++s) b += bias_part[(long)s * N1 + gid];
+        b *= scale;
+        dbias[gid] = accumulate ? dbias[gid] + b : b;
+    }
+    const long idx4 = gid * 4;
     if (idx4 >= n_elems) return;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nsplit; ++s) v += ld4(S + (long)s * n_elems + idx4);
@@ -418,27 +429,60 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     const int nzb = a->nzb > 0 ? a->nzb : 1;
     p.a_zb = a->a_zb; p.a_zg = a->a_zg; p.b_zb = a->b_zb; p.b_zg = a->b_zg; p.c_zb = a->c_zb; p.c_zg = a->c_zg; p.bias_zg = a->bias_zg;
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
-    p.tiles_m = (p.M + 127) / 128; p.tiles_n = (p.N + 127) / 128;
-    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(256);
-    const size_t lds = 4 * 128 * 128;
-    if (a->in_dtype == TAV_BF16) {
-        if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<bf16, bf16>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<bf16, float>), grid, block, lds, stream, p);
-    } else {
-        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, lds, stream, p);
+    p.tiles_n = (p.N + 127) / 128;
+    // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
+    int tm = a->tile_m_hint;
+    if (tm < 2 || tm > 4) {
+        double best = 1e30;
+        for (int c = 4; c >= 2; --c) {
+            const long tiles = (long)((p.M + 32 * c - 1) / (32 * c)) * p.tiles_n * nzb * p.nzg;
+            const double cost = (double)((tiles + 255) / 256) * (c + 0.8);
+            if (cost < best - 1e-9) { best = cost; tm = c; }
+        }
     }
+    p.tiles_m = (p.M + 32 * tm - 1) / (32 * tm);
+    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(256);
+    const size_t lds = 2 * (32 * tm + 128) * 128;
+#define TAV_NT_LAUNCH(TT, TOO)                                                                              \
+    do {                                                                                                    \
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4>), grid, block, lds, stream, p);          \
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3>), grid, block, lds, stream, p);     \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2>), grid, block, lds, stream, p);                  \
+    } while (0)
+    if (a->in_dtype == TAV_BF16) {
+        if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
+        else TAV_NT_LAUNCH(bf16, float);
+    } else {
+        TAV_NT_LAUNCH(float, float);
+    }
+#undef TAV_NT_LAUNCH
     return (int)hipGetLastError();
 }
 
 extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit) {
     if (!chunk_rows || !nsplit || n1 <= 0 || n2 <= 0 || rows_per_batch <= 0 || nbatch <= 0) return TAV_ERR_SHAPE;
     const long tiles = ((n1 + 127) / 128) * ((n2 + 127) / 128);
-    // aim at ~2 workgroups per CU (512), at least 256 tokens per split
-    long want = (512 + tiles - 1) / tiles;
-    long per_batch = (want + nbatch - 1) / nbatch;
-    if (per_batch < 1) per_batch = 1;
-    long cr = (rows_per_batch + per_batch - 1) / per_batch;
-    if (cr < 256) cr = 256;
+    // The kernel is resident at 2 workgroups per CU = 512 slots.  Pick the number of token chunks per batch entry so that
+    // tiles * splits fills whole rounds of 512 (a 576-workgroup launch costs two rounds), chunks stay >= 256 tokens, and among
+    // equally efficient choices the one with fewer splits (less slab traffic) wins.
+    const long SLOTS = 512;
+    long best_cpb = 1; double best_score = -1.0;
+    const long max_cpb = (rows_per_batch + 255) / 256 > 0 ? (rows_per_batch + 255) / 256 : 1;
+    for (long cpb = 1; cpb <= max_cpb && cpb <= 64; ++cpb) {
+        long cr = (rows_per_batch + cpb - 1) / cpb;
+        cr = ((cr + 63) / 64) * 64;
+        const long real_cpb = (rows_per_batch + cr - 1) / cr;
+        const long wgs = tiles * real_cpb * nbatch;
+        const long rounds = (wgs + SLOTS - 1) / SLOTS;
+        double eff = (double)wgs / (double)(rounds * SLOTS);
+        // per-round cost grows with the chunk length; total ~ rounds * cr; smaller is better.  Normalise by the ideal.
+        const double work = (double)rounds * (double)cr;
+        const double ideal = (double)tiles * nbatch * rows_per_batch / SLOTS;
+        double score = ideal / work - 0.004 * (double)(real_cpb * nbatch);      // mild penalty per split (slab bytes)
+        (void)eff;
+        if (score > best_score + 1e-9) { best_score = score; best_cpb = real_cpb; }
+    }
+    long cr = (rows_per_batch + best_cpb - 1) / best_cpb;
     cr = ((cr + 63) / 64) * 64;
     const long cpb = (rows_per_batch + cr - 1) / cr;
     *chunk_rows = (int32_t)cr;
@@ -481,10 +525,7 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     if (outer > 1 && inner * outer != p.N2) return TAV_ERR_SHAPE;
     const long nthreads = (n_elems + 3) / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a->slabs, a->out, nsplit,
-                       n_elems, p.N2, inner, outer, a->accumulate, a->scale == 0.f ? 1.f : a->scale);
-    if (a->dbias)
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)((p.N1 + 255) / 256)), dim3(256), 0, stream, a->bias_partials, a->dbias, nsplit, p.N1,
-                           a->accumulate, a->scale == 0.f ? 1.f : a->scale);
+                       n_elems, p.N2, inner, outer, a->accumulate, a->scale == 0.f ? 1.f : a->scale, (const float*)a->bias_partials, a->dbias, p.N1);
     return (int)hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ def profile_stop():
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None, want_pre=False, out=None,
             accumulate=False, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None):
+            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None, tile_m=0):
     """C = epi(alpha * A @ B^T).  Plain use: a [M,K], b [N,K] contiguous.  Strided/batched use: pass sizes/strides."""
     if M is None:
         M, K = a.shape[-2], a.shape[-1]
@@ -69,6 +69,7 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
     g.nzb, g.nzg = nzb, nzg
     g.a_zb, g.a_zg, g.b_zb, g.b_zg, g.c_zb, g.c_zg, g.bias_zg = a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg
     g.in_dtype, g.out_dtype, g.act, g.accumulate, g.alpha = dt(a), dt(out), act, int(accumulate), alpha
+    g.tile_m_hint = tile_m
     if bias is not None:
         assert bias.dtype == torch.float32
     if resid is not None:

@@ -32,13 +32,13 @@ def tol_for(dtype):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-def check_gemm_nt(dtype, M=300, N=256, K=128, bias=True, act=0, resid=True, pre=False, out_f32=False):
+def check_gemm_nt(dtype, M=300, N=256, K=128, bias=True, act=0, resid=True, pre=False, out_f32=False, tile_m=0):
     a = _rnd(M, K, dtype=dtype, seed=1)
     b = _rnd(N, K, dtype=dtype, scale=0.1, seed=2)
     bi = _rnd(N, seed=3) if bias else None
     r = _rnd(M, N, seed=4) if resid else None
     out_dtype = torch.float32 if (out_f32 or dtype == torch.float32) else dtype
-    res = ops.gemm_nt(a, b, bias=bi, act=act, resid=r, want_pre=pre, out_dtype=out_dtype)
+    res = ops.gemm_nt(a, b, bias=bi, act=act, resid=r, want_pre=pre, out_dtype=out_dtype, tile_m=tile_m)
     out, p = res if pre else (res, None)
     ref = a.float() @ b.float().t()
     if bias:
@@ -49,7 +49,7 @@ def check_gemm_nt(dtype, M=300, N=256, K=128, bias=True, act=0, resid=True, pre=
     if resid:
         ref = ref + r
     tol = tol_for(dtype if out_dtype != torch.float32 else torch.float32) if dtype == torch.float32 else (1e-2 if out_dtype == torch.bfloat16 else 2e-3)
-    rs = [_res(f"gemm_nt[{dtype},M{M},N{N},K{K},b{int(bias)},a{act},r{int(resid)},f32out{int(out_f32)}]", out, ref, tol)]
+    rs = [_res(f"gemm_nt[{dtype},M{M},N{N},K{K},b{int(bias)},a{act},r{int(resid)},f32out{int(out_f32)},tm{tile_m}]", out, ref, tol)]
     if pre:
         rs.append(_res("gemm_nt.pre", p, ref_pre, tol))
     return rs
@@ -346,6 +346,8 @@ def all_checks():
         out.append(lambda d=dtype: check_gemm_nt(d))
         out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=768, K=768, act=1, pre=True, resid=False))
         out.append(lambda d=dtype: check_gemm_nt(d, M=129, N=2304, K=768, resid=False))
+        for tmh in (2, 3, 4):
+            out.append(lambda d=dtype, t=tmh: check_gemm_nt(d, M=333, N=384, K=256, tile_m=t))
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_tn(d))
         out.append(lambda d=dtype: check_gemm_tn(d, M=249, N1=768, N2=512, nbatch=3))

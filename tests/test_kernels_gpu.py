@@ -9,7 +9,7 @@ def _cases():
     return kernel_checks.all_checks()
 
 
-@pytest.mark.parametrize("idx", range(64))
+@pytest.mark.parametrize("idx", range(80))
 def test_kernel_check(gpu, idx):
     cases = _cases()
     if idx >= len(cases):

@@ -37,7 +37,10 @@ for dtype in (torch.bfloat16, torch.float32):
         a, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype)
         bias = torch.randn(N, device=dev)
         t = timeit(lambda: ops.gemm_nt(a, b, bias=bias))
-        print(f"gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+        extra = ""
+        if dtype == torch.bfloat16:
+            extra = "   [tile_m 2/3/4: " + " ".join(f"{timeit(lambda tm=tm: ops.gemm_nt(a, b, bias=bias, tile_m=tm))*1e6:.1f}" for tm in (2, 3, 4)) + " us]"
+        print(f"gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TFLOP/s{extra}")
     for (name, M, N1, N2) in [("video dWqkv", B * 1464, 2304, 768), ("video dWo", B * 1464, 768, 768), ("video dW1", B * 1464, 3072, 768),
                               ("video dW2", B * 1464, 768, 3072), ("text dW1", B * 128, 3072, 768)]:
         a, b = rnd(M, N1, dtype=dtype), rnd(M, N2, dtype=dtype)
