@@ -272,9 +272,11 @@ int tav_sumsq_multi(const float* const* ptrs, const int64_t* sizes, int32_t nten
 /* p -= lr*(m_hat/(sqrt(v_hat)+eps)) after p *= (1-lr*wd); grads scaled by *clip_coef_ptr (device scalar, computed by
  * tav_clip_coef from the global norm) so no host sync is needed between norm and step. */
 int tav_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream);
+/* lr (f32 scalar), step (int32 counter, incremented by the call) and bias_corr (2 f32 of scratch) live on the DEVICE so that a
+ * captured hipGraph replays with the right learning rate and bias correction (kernel arguments are frozen under replay). */
 int tav_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
-                    int32_t ntensors, const float* clip_coef /*opt*/, float lr, float beta1, float beta2, float eps, float weight_decay,
-                    int32_t step, void* stream);
+                    int32_t ntensors, const float* clip_coef /*opt*/, const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                    int32_t* step, float* bias_corr, void* stream);
 
 #ifdef __cplusplus
 }

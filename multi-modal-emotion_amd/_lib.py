@@ -106,7 +106,7 @@ _SIGS = {
     "tav_sumsq_partials": (C.c_int, [i32]),
     "tav_sumsq_multi": (C.c_int, [vp, vp, i32, vp, vp, vp]),
     "tav_clip_coef": (C.c_int, [vp, f32, vp, vp, vp]),
-    "tav_adamw_multi": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, f32, i32, vp]),
+    "tav_adamw_multi": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
 }
 
 _lib = None

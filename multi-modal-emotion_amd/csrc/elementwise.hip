@@ -325,10 +325,18 @@ __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef
     float c = max_norm / (norm + 1e-6f);            // torch.nn.utils.clip_grad_norm_
     coef[0] = c < 1.f ? c : 1.f;
 }
+// step counter lives on the device so that a captured hipGraph replays with the right bias correction
+__global__ void adam_tick_kernel(int* step, float b1, float b2, float* bc) {
+    const int s = step[0] + 1;
+    step[0] = s;
+    bc[0] = 1.f - powf(b1, (float)s);
+    bc[1] = 1.f - powf(b2, (float)s);
+}
 __global__ __launch_bounds__(256) void adamw_multi_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
                                                           float* const* __restrict__ m1, float* const* __restrict__ m2, const int64_t* __restrict__ sizes,
-                                                          const float* __restrict__ clip_coef, float lr, float b1, float b2, float eps, float wd,
-                                                          float bc1, float bc2) {
+                                                          const float* __restrict__ clip_coef, const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                                                          float wd, const float* __restrict__ bc) {
+    const float lr = lr_dev[0], bc1 = bc[0], bc2 = bc[1];
     const int t = blockIdx.y;
     float* p = params[t]; const float* g = grads[t]; float* ea = m1[t]; float* es = m2[t];
     const long n = sizes[t];
@@ -540,12 +548,12 @@ extern "C" int tav_clip_coef(const float* sumsq, float max_norm, float* coef_out
     return tav_last_error();
 }
 extern "C" int tav_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
-                               int32_t ntensors, const float* clip_coef, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                               void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes) return TAV_ERR_NULL;
-    if (ntensors <= 0 || ntensors > 65535 || step <= 0) return TAV_ERR_SHAPE;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+                               int32_t ntensors, const float* clip_coef, const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                               int32_t* step, float* bias_corr, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !lr || !step || !bias_corr) return TAV_ERR_NULL;
+    if (ntensors <= 0 || ntensors > 65535) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ST, step, beta1, beta2, bias_corr);
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(192, ntensors), dim3(256), 0, ST, params, grads, exp_avg, exp_avg_sq, sizes, clip_coef, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2);
+                       weight_decay, (const float*)bias_corr);
     return tav_last_error();
 }

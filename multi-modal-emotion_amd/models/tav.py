@@ -58,10 +58,9 @@ class PreFormer(nn.Module):
     def _get_feature_vector_attention_mask(self, feature_vector_length, attention_mask, add_adapter=None):
         non_padded = attention_mask.cumsum(dim=-1)[:, -1]
         out_len = self._get_feat_extract_output_lengths(non_padded).to(torch.long)
-        B = attention_mask.shape[0]
-        m = torch.zeros((B, feature_vector_length), dtype=attention_mask.dtype, device=attention_mask.device)
-        m[(torch.arange(B, device=m.device), out_len - 1)] = 1
-        return m.flip([-1]).cumsum(-1).flip([-1]).bool()
+        # same result as the reference's "set index out_len-1, flip, cumsum, flip" (:337-341) without an index_put, which
+        # synchronises the host and cannot be captured into a hipGraph
+        return torch.arange(feature_vector_length, device=attention_mask.device)[None, :] < out_len[:, None]
 
     def _mask_hidden_states(self, hidden, B, T, attention_mask, training=False):
         """SpecAugment along time (models/tav.py:269-306).  Host-side index sampling as in the reference (numpy RNG);

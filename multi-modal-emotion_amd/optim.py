@@ -31,9 +31,10 @@ class FusedAdamW:
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = {}
-        self.step_count = 0
         self._tables = None
         self.last_norm = None
+        self._lr_dev = None          # device copies of lr / step counter: graph replay must not bake them into kernel args
+        self._lr_host = None
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -47,7 +48,9 @@ class FusedAdamW:
         n = len(act)
         if self._tables is None or self._tables[0].host.numel() < n:
             self._tables = tuple(_PtrTable(max(n, len(self.params)), dev) for _ in range(5))
-            self._scal = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._scal = torch.zeros(8, dtype=torch.float32, device=dev)
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._lr_pin = torch.empty(1, dtype=torch.float32).pin_memory()
         for p in act:
             if p not in self.state:
                 self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
@@ -76,14 +79,21 @@ class FusedAdamW:
             check(lib().tav_clip_coef(ptr(self._scal[0:1]), float(max_norm), ptr(self._scal[1:2]), ptr(self._scal[2:3]), stream()), "clip_coef")
             coef = self._scal[1:2]
             self.last_norm = self._scal[2:3]
-        self.step_count += 1
-        check(lib().tav_adamw_multi(ptr(d_p), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_s), n, ptr(coef), self.lr, self.betas[0], self.betas[1], self.eps,
-                                    self.weight_decay, self.step_count, stream()), "adamw_multi")
+        if self._lr_host != self.lr:                # refresh the device-side learning rate only when the schedule moved it
+            self._lr_pin[0] = self.lr
+            self._scal[4:5].copy_(self._lr_pin, non_blocking=True)
+            self._lr_host = self.lr
+        check(lib().tav_adamw_multi(ptr(d_p), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_s), n, ptr(coef), ptr(self._scal[4:5]), self.betas[0], self.betas[1],
+                                    self.eps, self.weight_decay, ptr(self._step_dev), ptr(self._scal[5:7]), stream()), "adamw_multi")
         engine.bump_weight_epoch()          # parameters changed through raw pointers: refresh cached operand copies
         return self.last_norm
 
     def step(self):
         return self.clip_and_step(None)
+
+    @property
+    def step_count(self):
+        return int(self._step_dev.item()) if self._tables is not None else 0
 
 
 def grad_norm(params):

@@ -49,7 +49,7 @@ def get_statistics(input, label, model, PREFormer, criterion, Metric, check="tra
                    video_embeds=video_input_ids.to(device), visual_mask=video_attention_mask.to(device), hidden_states=tav.to(device),
                    pos_embed=tav_embed.to(device), attention_mask=attention_mask.to(device), batch_size=batch_size, check=check,
                    n_visual_true=n_visual_true)
-    label = label.type(torch.LongTensor).to(device)
+    label = label.to(device).long()          # (the reference's .type(torch.LongTensor) would bounce through the host)
     if Metric is not None:
         Metric.update_metrics(torch.argmax(output, dim=1), label.long())
     batch_loss = None
