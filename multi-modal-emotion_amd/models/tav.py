@@ -78,6 +78,8 @@ class PreFormer(nn.Module):
         """n_visual_true (optional): number of True entries per row of visual_mask; passing it avoids one host sync."""
         dev = _dev(device if str(device) != "cpu" else None)
         ectx = runtime.ctx()
+        if audio_features.is_cuda:
+            runtime.mark_inputs_ready()
         B = audio_features.shape[0]
         parts = []
         St = 0
@@ -165,14 +167,41 @@ class TAVForMAE(nn.Module):
                 batch_size=2, check="train", n_visual_true=None):
         dev = _dev(hidden_states.device if hidden_states.is_cuda else None)
         B, Sf, _ = hidden_states.shape
-        av = E.EmbedAddFn.apply(hidden_states.to(dev).reshape(B * Sf, 768), pos_embed.to(dev).reshape(-1).contiguous(), self.embedding.weight)   # :474
-        aud, aud_lp, Sa = self.wav2vec2(audio_features.to(dev, torch.float32))          # :476
         ectx = runtime.ctx()
-        aud = E.LinearFn.apply(aud, aud_lp if not ectx.pol.f32 else None, self.wav_2_768_2.weight, self.wav_2_768_2.bias, None, ectx, True)   # :478
         nkeep = None if n_visual_true is None else visual_mask.shape[1] - n_visual_true
-        vid, Sv = self.videomae(video_embeds.to(dev, torch.float32), visual_mask.to(dev), nkeep)    # :480
-        _, t = self.bert(input_ids.to(dev), text_attention_mask.to(dev))                # :485
-        av = self.random_mae_encoder(av.view(B, Sf, 768), attention_mask.to(dev))       # :487
+        audio_features, video_embeds = audio_features.to(dev, torch.float32), video_embeds.to(dev, torch.float32)
+        visual_mask, input_ids, text_attention_mask = visual_mask.to(dev), input_ids.to(dev), text_attention_mask.to(dev)
+
+        def audio_branch():
+            a, a_lp, sa = self.wav2vec2(audio_features)                                  # :476
+            return E.LinearFn.apply(a, a_lp if not ectx.pol.f32 else None, self.wav_2_768_2.weight, self.wav_2_768_2.bias, None, ectx, True), sa   # :478
+
+        main = torch.cuda.current_stream()
+        if runtime.multistream[0]:
+            ev = runtime.take_inputs_event()
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+            s_aud, s_vid, s_txt = runtime.branch_streams(3)
+            with torch.cuda.stream(s_vid):
+                s_vid.wait_event(ev)
+                vid, Sv = self.videomae(video_embeds, visual_mask, nkeep)                # :480
+            with torch.cuda.stream(s_aud):
+                s_aud.wait_event(ev)
+                aud, Sa = audio_branch()
+            with torch.cuda.stream(s_txt):
+                s_txt.wait_event(ev)
+                _, t = self.bert(input_ids, text_attention_mask)                         # :485
+        else:
+            aud, Sa = audio_branch()
+            vid, Sv = self.videomae(video_embeds, visual_mask, nkeep)
+            _, t = self.bert(input_ids, text_attention_mask)
+        av = E.EmbedAddFn.apply(hidden_states.to(dev).reshape(B * Sf, 768), pos_embed.to(dev).reshape(-1).contiguous(), self.embedding.weight)   # :474
+        av = self.random_mae_encoder(av.view(B, Sf, 768), attention_mask.to(dev))       # :487 (fusion branch stays on the caller's stream)
+        if runtime.multistream[0]:
+            for st, ten in ((s_aud, aud), (s_vid, vid), (s_txt, t)):
+                main.wait_stream(st)
+                ten.record_stream(main)
         p_drop = self.dropout_p if check == "train" else 0.0
         self._drop_calls += 1
         seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._drop_calls) & 0xFFFFFFFFFFFFFFFF

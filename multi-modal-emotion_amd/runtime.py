@@ -20,3 +20,34 @@ def ctx():
 
 def precision():
     return ctx().pol.name
+
+
+# ---- branch streams: text / audio / video encoders run beside the fusion encoder (reference models/tav.py:476-487 are
+# four independent sub-graphs that meet only at the concat, :495).  Autograd replays each branch's backward on the stream its
+# forward used, so the backward overlaps the same way; under hipGraph capture the fork/join becomes parallel graph branches.
+_streams = {}
+_inputs_event = [None]
+multistream = [True]
+
+
+def branch_streams(n=3):
+    import torch
+    dev = torch.cuda.current_device()
+    if dev not in _streams:
+        _streams[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _streams[dev]
+
+
+def mark_inputs_ready():
+    """Record 'the batch is resident' on the current stream (called at the start of PreFormer.forward): the encoder branches of
+    TAVForMAE wait for this event only, not for PreFormer's own kernels."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _inputs_event[0] = ev
+    return ev
+
+
+def take_inputs_event():
+    ev, _inputs_event[0] = _inputs_event[0], None
+    return ev
