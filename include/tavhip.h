@@ -160,6 +160,10 @@ int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, vo
 /* generic strided cast/copy: dst[r][c] = src[r][c] for r<R, c<C (dtypes may differ) */
 int tav_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst, int64_t R, int64_t C,
                void* stream);
+/* dst[z][c][r] = src[z][r][c] for z < nbatch.  The reference's TransformerEncoder "concat" (utils/TAVFormer.py:84) does
+ * scores[B*h,S,d].transpose(1,2).contiguous().view(B,S,h*d): per batch that is exactly the [S,H] -> [H,S] transpose of the
+ * token-major attention output, re-read as [S,H]. */
+int tav_transpose2d(const void* src, void* dst, int32_t dtype, int64_t R, int64_t C, int64_t nbatch, void* stream);
 /* y_f32 = a + b (f32) and optional low-precision copy */
 int tav_add_f32(const float* a, const float* b, float* y, void* y_lp, int32_t lp_dtype, int64_t n, void* stream);
 /* fill f32 */

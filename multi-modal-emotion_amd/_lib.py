@@ -71,6 +71,7 @@ _SIGS = {
     "tav_cast_weight": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i32, vp]),
     "tav_cast_conv_weight": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp]),
     "tav_cast2d": (C.c_int, [vp, i32, i64, vp, i32, i64, i64, i64, vp]),
+    "tav_transpose2d": (C.c_int, [vp, vp, i32, i64, i64, i64, vp]),
     "tav_add_f32": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),
     "tav_fill_f32": (C.c_int, [vp, f32, i64, vp]),
     "tav_embed_add_fwd": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),

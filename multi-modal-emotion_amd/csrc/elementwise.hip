@@ -41,6 +41,24 @@ __global__ void cast_conv_weight_kernel(const float* __restrict__ src, TD* __res
     if (dst_t) ET<TD>::st(dst_t + ((long)kk * CI + ci) * CO + co, v);
 }
 
+// dst[z][c][r] = src[z][r][c]  (batched 2-D transpose through a padded LDS tile; both sides coalesced)
+template <typename T>
+__global__ void transpose2d_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int C) {
+    __shared__ float tile[32][33];
+    const long zoff = (long)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? ET<T>::ld(src + zoff + (long)r * C + c) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < C) ET<T>::st(dst + zoff + (long)c * R + r, tile[tx][k]);
+    }
+}
+
 template <typename TS, typename TD>
 __global__ void cast2d_kernel(const TS* __restrict__ src, long ld_src, TD* __restrict__ dst, long ld_dst, long R, int C4) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,6 +417,15 @@ extern "C" int tav_cast2d(const void* src, int32_t sdt, int64_t ld_src, void* ds
     else if (sdt == TAV_BF16 && ddt == TAV_F32) hipLaunchKernelGGL((cast2d_kernel<bf16, float>), G1(n), (const bf16*)src, (long)ld_src, (float*)dst, (long)ld_dst, (long)R, (int)(C / 4));
     else if (sdt == TAV_F32 && ddt == TAV_F32) hipLaunchKernelGGL((cast2d_kernel<float, float>), G1(n), (const float*)src, (long)ld_src, (float*)dst, (long)ld_dst, (long)R, (int)(C / 4));
     else if (sdt == TAV_BF16 && ddt == TAV_BF16) hipLaunchKernelGGL((cast2d_kernel<bf16, bf16>), G1(n), (const bf16*)src, (long)ld_src, (bf16*)dst, (long)ld_dst, (long)R, (int)(C / 4));
+    else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+extern "C" int tav_transpose2d(const void* src, void* dst, int32_t dt, int64_t R, int64_t C, int64_t nbatch, void* stream) {
+    if (!src || !dst) return TAV_ERR_NULL;
+    if (R <= 0 || C <= 0 || nbatch <= 0 || nbatch > 65535) return TAV_ERR_SHAPE;
+    dim3 grid(tav_cdiv(C, 32), tav_cdiv(R, 32), (unsigned)nbatch);
+    if (dt == TAV_BF16) hipLaunchKernelGGL((transpose2d_kernel<bf16>), grid, dim3(256), 0, ST, (const bf16*)src, (bf16*)dst, (int)R, (int)C);
+    else if (dt == TAV_F32) hipLaunchKernelGGL((transpose2d_kernel<float>), grid, dim3(256), 0, ST, (const float*)src, (float*)dst, (int)R, (int)C);
     else return TAV_ERR_DTYPE;
     return tav_last_error();
 }

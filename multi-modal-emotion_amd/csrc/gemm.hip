@@ -12,6 +12,7 @@
 // K-tile = 128 bytes per row (64 bf16 / 32 f32), register-staged global->LDS double buffer, one barrier per K-tile.
 // LDS image of the NT kernel: [row][8 chunks of 16 B], chunk index XOR-swizzled with (row>>1)&7 so that the
 // ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group) are bank-conflict free.
+#include <stdlib.h>
 #include "common.h"
 #include "tavhip_internal.h"
 
@@ -459,6 +460,12 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     return (int)hipGetLastError();
 }
 
+static double split_penalty() {
+    static double v = -1.0;
+    if (v < 0.0) { const char* e = getenv("TAV_TN_SPLIT_PENALTY"); v = e ? atof(e) : 0.06; }   // tuned with the four branch streams running concurrently
+    return v;
+}
+
 extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit) {
     if (!chunk_rows || !nsplit || n1 <= 0 || n2 <= 0 || rows_per_batch <= 0 || nbatch <= 0) return TAV_ERR_SHAPE;
     const long tiles = ((n1 + 127) / 128) * ((n2 + 127) / 128);
@@ -478,7 +485,7 @@ extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch
         // per-round cost grows with the chunk length; total ~ rounds * cr; smaller is better.  Normalise by the ideal.
         const double work = (double)rounds * (double)cr;
         const double ideal = (double)tiles * nbatch * rows_per_batch / SLOTS;
-        double score = ideal / work - 0.004 * (double)(real_cpb * nbatch);      // mild penalty per split (slab bytes)
+        double score = ideal / work - split_penalty() * (double)(real_cpb * nbatch);      // penalty per split (slab bytes)
         (void)eff;
         if (score > best_score + 1e-9) { best_score = score; best_cpb = real_cpb; }
     }

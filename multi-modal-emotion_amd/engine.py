@@ -598,3 +598,82 @@ class CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, g):
         (dlog,) = ctx.saved_tensors
         return dlog * g, None, None
+
+
+# ---------------------------------------------------------------------------------------------- TransformerBlock (alt. fusion stack)
+class TransformerBlockFn(torch.autograd.Function):
+    """One block of the reference's TransformerEncoder (utils/TAVFormer.py:93-142 with MultiHeadAttention :10-90):
+        a  = Wo . scramble(attn(x Wq, x Wk, x Wv; additive key mask BEFORE softmax)) + bo          bias-free q/k/v (:24-26)
+        n1 = LN1(dropout1(x + a));   f = W2 . gelu(W1 . dropout_f(n1) + b1) + b2;   out = LN2(dropout2(f + n1))
+    `scramble` is the reference's `scores[B*h,S,d].transpose(1,2).contiguous().view(B,S,h*d)` (:84): per batch the [S,H] -> [H,S]
+    transpose of the token-major attention output re-read as [S,H].  early_div (:45-46 vs :62-63) divides by sqrt(64) = 8, an exact
+    power of two, so both orders give bit-identical results and share one code path.
+    params = (wq, wk, wv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b); p_drop > 0 draws three masks from `seed`."""
+
+    @staticmethod
+    def forward(ctx, x, key_mask, ectx, B, S, nh, p_drop, seed, *params):
+        pol, cache = ectx.pol, ectx.cache
+        wq, wk, wv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b = params
+        H = nh * 64
+        x = _c(x)
+        x_lp = _to_lp(pol, x)
+        wqkv, _, _ = cache.qkv(wq, wk, wv, None, None, None)
+        wo_n, _ = cache.linear(wo)
+        w1_n, _ = cache.linear(w1)
+        w2_n, _ = cache.linear(w2)
+        qkv = ops.gemm_nt(x_lp, wqkv)
+        mode = 1 if key_mask is not None else 0
+        o, lse, _ = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=mode)
+        o_scr = ops.transpose2d(o, S, H, B)
+        y1 = ops.gemm_nt(o_scr, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
+        m1 = m2 = m3 = None
+        if p_drop > 0:
+            y1, m1 = ops.dropout_fwd(y1, p_drop, seed, 0)
+        n1, n1_lp, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, 1e-5, need_f32=True)
+        f_in = n1_lp
+        if p_drop > 0:
+            d, m2 = ops.dropout_fwd(n1, p_drop, seed, 1 << 40)
+            f_in = _to_lp(pol, d)
+        h, u = ops.gemm_nt(f_in, w1_n, bias=b1, act=1, want_pre=True)
+        y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=n1, out_dtype=torch.float32)
+        if p_drop > 0:
+            y2, m3 = ops.dropout_fwd(y2, p_drop, seed, 2 << 40)
+        out, _, mean2, rstd2 = _ln_fwd(pol, y2, ln2_w, ln2_b, 1e-5, need_f32=True)
+        ctx.ectx, ctx.geom = ectx, (B, S, nh, p_drop, mode)
+        ctx.save_for_backward(x_lp, qkv, o, o_scr, lse, y1, f_in, u, h, y2, mean1, rstd1, mean2, rstd2, key_mask, m1, m2, m3, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pol, cache = ctx.ectx.pol, ctx.ectx.cache
+        B, S, nh, p_drop, mode = ctx.geom
+        sv = ctx.saved_tensors
+        x_lp, qkv, o, o_scr, lse, y1, f_in, u, h, y2, mean1, rstd1, mean2, rstd2, key_mask, m1, m2, m3 = sv[:18]
+        wq, wk, wv, wo, bo, ln1_w, ln1_b, w1, b1, w2, b2, ln2_w, ln2_b = sv[18:]
+        H = nh * 64
+        _, wqkv_t, _ = cache.qkv(wq, wk, wv, None, None, None)
+        _, wo_t = cache.linear(wo)
+        _, w1_t = cache.linear(w1)
+        _, w2_t = cache.linear(w2)
+        dy2, _, dg2, db2 = _ln_bwd(pol, _c(g), y2, ln2_w, ln2_b, mean2, rstd2, need_lp=False)
+        if m3 is not None:
+            dy2 = ops.dropout_bwd(dy2, m3, p_drop)
+        dy2_lp = _to_lp(pol, dy2)
+        dW2, dB2 = ops.gemm_tn(dy2_lp, h, want_bias=True)
+        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
+        dW1, dB1 = ops.gemm_tn(du, f_in, want_bias=True)
+        df = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)               # grad wrt dropout_f(n1)
+        if m2 is not None:
+            df = ops.dropout_bwd(df, m2, p_drop)
+        dn1, _ = ops.add_f32(df, dy2)                                      # + residual path (f + n1)
+        dy1, _, dg1, db1 = _ln_bwd(pol, dn1, y1, ln1_w, ln1_b, mean1, rstd1, need_lp=False)
+        if m1 is not None:
+            dy1 = ops.dropout_bwd(dy1, m1, p_drop)
+        dy1_lp = _to_lp(pol, dy1)
+        dWo, dBo = ops.gemm_tn(dy1_lp, o_scr, want_bias=True)
+        do_scr = ops.gemm_nt(dy1_lp, wo_t)
+        do = ops.transpose2d(do_scr, H, S, B)                              # inverse of the scramble
+        dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, None, B, S, nh, key_mask=key_mask, mask_mode=mode)
+        dWqkv = ops.gemm_tn(dqkv, x_lp)
+        g0 = ops.gemm_nt(dqkv, wqkv_t, resid=dy1, out_dtype=torch.float32)
+        return (g0, None, None, None, None, None, None, None, dWqkv[:H], dWqkv[H:2 * H], dWqkv[2 * H:], dWo, dBo, dg1, db1, dW1, dB1, dW2, dB2, dg2, db2)

@@ -83,25 +83,45 @@ class PreFormer(nn.Module):
         B = audio_features.shape[0]
         parts = []
         St = 0
+        audio_features, video_embeds, visual_mask = audio_features.to(dev, torch.float32), video_embeds.to(dev, torch.float32), visual_mask.to(dev)
+        Sa = self.wav2vec2.conv_out_len(audio_features.shape[1])
+        if audio_mask is not None:
+            audio_mask = self._get_feature_vector_attention_mask(Sa, audio_mask.to(dev))     # :355 bool [B, Sa]
+
+        def audio_frontend():
+            feats = self.wav2vec2.feature_extractor_fwd(audio_features)                 # :352  [B, Sa, 512]
+            hidden = self.wav2vec2.feature_projection_fwd(feats)                        # :356  f32 [B*Sa, Ha]
+            hidden = self._mask_hidden_states(hidden, B, Sa, audio_mask, train)         # :359
+            hidden = self.wav2vec2.pos_conv_fwd(hidden, B, Sa)                          # :360
+            enc = self.wav2vec2.encoder
+            hidden, hidden_lp = E.layer_norm_f32(ectx, hidden, enc.layer_norm.weight, enc.layer_norm.bias, self.cfg["audio"]["eps"])   # :361
+            return E.LinearFn.apply(hidden, hidden_lp if not ectx.pol.f32 else None, self.wav_2_768.weight, self.wav_2_768.bias, None, ectx, True)   # :363
+
+        main = torch.cuda.current_stream()
+        side = runtime.multistream[0] and runtime.front_side[0] and audio_features.is_cuda
+        if side:        # the three front-ends are independent (models/tav.py:349-368): audio and video on side streams, text here
+            ev = torch.cuda.Event()
+            ev.record(main)
+            s_a, s_v = runtime.front_streams(2)
+            with torch.cuda.stream(s_a):
+                s_a.wait_event(ev)
+                x_audio = audio_frontend()
+            with torch.cuda.stream(s_v):
+                s_v.wait_event(ev)
+                x_video, Nv = self.videomae.embed(video_embeds, ~visual_mask, n_visual_true)   # :368
         if input_ids is not None:
             input_ids = input_ids.to(dev)
             x_text, _ = self.bert.embed(input_ids)                                      # :349
             St = input_ids.shape[1]
             parts.append(x_text)
-        feats = self.wav2vec2.feature_extractor_fwd(audio_features.to(dev, torch.float32))   # :352  [B, Sa, 512]
-        Sa = feats.shape[1]
-        if audio_mask is not None:
-            audio_mask = self._get_feature_vector_attention_mask(Sa, audio_mask.to(dev))     # :355 bool [B, Sa]
-        hidden = self.wav2vec2.feature_projection_fwd(feats)                            # :356  f32 [B*Sa, Ha]
-        hidden = self._mask_hidden_states(hidden, B, Sa, audio_mask, train)             # :359
-        hidden = self.wav2vec2.pos_conv_fwd(hidden, B, Sa)                              # :360
-        enc = self.wav2vec2.encoder
-        hidden, hidden_lp = E.layer_norm_f32(ectx, hidden, enc.layer_norm.weight, enc.layer_norm.bias, self.cfg["audio"]["eps"])   # :361
-        x_audio = E.LinearFn.apply(hidden, hidden_lp if not ectx.pol.f32 else None, self.wav_2_768.weight, self.wav_2_768.bias, None, ectx, True)   # :363
-        parts.append(x_audio)
-        visual_mask = visual_mask.to(dev)
-        x_video, Nv = self.videomae.embed(video_embeds.to(dev, torch.float32), ~visual_mask, n_visual_true)   # :368
-        parts.append(x_video)
+        if side:
+            for st, ten in ((s_a, x_audio), (s_v, x_video)):
+                main.wait_stream(st)
+                ten.record_stream(main)
+        else:
+            x_audio = audio_frontend()
+            x_video, Nv = self.videomae.embed(video_embeds, ~visual_mask, n_visual_true)
+        parts += [x_audio, x_video]
         tav = E.ConcatSeqFn.apply(B, *parts)                                            # :372-375
 
         # static modality ids and masks (:378-409) -- tiny host-logic tensors

@@ -231,6 +231,13 @@ def cast2d(x, dtype, out=None):
     return out
 
 
+def transpose2d(x, R, Cc, nbatch):
+    """x: [nbatch*R, Cc] -> per batch transposed [nbatch*Cc, R] (returned with the same 2-D shape as x: the reference re-views it)."""
+    out = torch.empty_like(x)
+    check(lib().tav_transpose2d(ptr(x), ptr(out), dt(x), R, Cc, nbatch, stream()), "transpose2d")
+    return out
+
+
 def add_f32(a, b, *, want_f32=True, lp_dtype=None):
     y = torch.empty_like(a) if want_f32 else None
     ylp = torch.empty(a.shape, dtype=lp_dtype, device=a.device) if lp_dtype is not None else None

@@ -30,12 +30,31 @@ _inputs_event = [None]
 multistream = [True]
 
 
+import os as _os
+
+front_side = [_os.environ.get("TAV_FRONT_STREAMS", "0") == "1"]     # PreFormer front-ends on side streams (measured: slower, off)
+_prio = _os.environ.get("TAV_STREAM_PRIO", "0") == "1"     # measured: priorities break the overlap under graph replay (55 vs 37.7 ms)
+
+
 def branch_streams(n=3):
+    """(audio, video, text) streams; the video branch is the critical path, so it gets the high priority."""
     import torch
     dev = torch.cuda.current_device()
     if dev not in _streams:
-        _streams[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        pr = [0, -1, 0] if _prio else [0, 0, 0]
+        _streams[dev] = [torch.cuda.Stream(device=dev, priority=pr[i]) for i in range(n)]
     return _streams[dev]
+
+
+_front = {}
+
+
+def front_streams(n=2):
+    import torch
+    dev = torch.cuda.current_device()
+    if dev not in _front:
+        _front[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _front[dev]
 
 
 def mark_inputs_ready():

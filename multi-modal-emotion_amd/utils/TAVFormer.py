@@ -96,3 +96,62 @@ class VideoMAEEncoder(nn.Module):
         if not return_dict:
             return tuple(v for v in [out, all_hidden] if v is not None)
         return out
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameter holder, reference names (utils/TAVFormer.py:10-28): bias-free query/key/value matrices + `out` with bias."""
+
+    def __init__(self, embed_dim=768, n_heads=12):
+        super().__init__()
+        self.embed_dim, self.n_heads = embed_dim, n_heads
+        self.single_head_dim = int(embed_dim / n_heads)
+        self.query_matrix = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.key_matrix = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.value_matrix = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.out = nn.Linear(embed_dim, embed_dim)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, embed_dim, expansion_factor=4, n_heads=12, dropout=0.2):
+        super().__init__()
+        self.dropout = dropout
+        self.attention = MultiHeadAttention(embed_dim, n_heads)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.feed_forward = nn.Sequential(nn.Dropout(dropout), nn.Linear(embed_dim, expansion_factor * embed_dim), nn.GELU(),
+                                          nn.Linear(expansion_factor * embed_dim, embed_dim))
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(embed_dim)
+
+    def params(self):
+        a, f = self.attention, self.feed_forward
+        return (a.query_matrix.weight, a.key_matrix.weight, a.value_matrix.weight, a.out.weight, a.out.bias, self.norm1.weight, self.norm1.bias,
+                f[1].weight, f[1].bias, f[3].weight, f[3].bias, self.norm2.weight, self.norm2.bias)
+
+
+class TransformerEncoder(nn.Module):
+    """Drop-in for reference utils/TAVFormer.py:144-166 (post-LN stack, additive mask [B,1,1,S] BEFORE softmax).  The reference
+    never calls .eval() on it, so its three dropouts per block stay active in training; here they follow `self.training`."""
+
+    def __init__(self, embed_dim, num_layers=2, expansion_factor=4, n_heads=12, dropout=0.2, early_div=False):
+        super().__init__()
+        if embed_dim != n_heads * 64:
+            raise ValueError("libtavhip attention is built for head_dim 64")
+        self.early_div = early_div            # /8 before or after q.k^T: bit-identical (exact power of two), one code path
+        self.n_heads, self.p = n_heads, dropout
+        self.layers = nn.ModuleList([TransformerBlock(embed_dim, expansion_factor, n_heads, dropout) for _ in range(num_layers)])
+        self._calls = 0
+
+    def forward(self, x, attention_mask=None):
+        if not x.is_cuda:
+            raise RuntimeError("TransformerEncoder runs on libtavhip (GPU) only; there is no CPU fallback")
+        ectx = runtime.ctx()
+        B, S, H = x.shape
+        key_mask = attention_mask.reshape(B, S).to(torch.float32).contiguous() if attention_mask is not None else None
+        p = self.p if self.training else 0.0
+        h = x.reshape(B * S, H)
+        for i, layer in enumerate(self.layers):
+            self._calls += 1
+            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._calls) & 0xFFFFFFFFFFFFFFFF
+            h = E.TransformerBlockFn.apply(h, key_mask, ectx, B, S, self.n_heads, p, seed, *layer.params())
+        return h.view(B, S, H)

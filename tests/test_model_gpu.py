@@ -15,7 +15,7 @@ from tav_amd import engine as E
 from tav_amd import runtime, synthetic
 from tav_amd.models.tav import PreFormer, TAVForMAE
 from tav_amd.optim import FusedAdamW, grad_norm
-from tav_amd.utils.TAVFormer import VideoMAEEncoder
+from tav_amd.utils.TAVFormer import TransformerEncoder, VideoMAEEncoder
 
 pytestmark = pytest.mark.gpu
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "tav_golden.npz"))
@@ -171,3 +171,34 @@ def test_fused_adamw_matches_torch(gpu):
         assert abs(n.item() - n_ref.item()) / n_ref.item() < 1e-5
         for p, q in zip(ps, qs):
             assert rel(p, q) < 1e-5
+
+
+@pytest.mark.parametrize("policy,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_transformer_encoder_vs_oracle_and_golden(gpu, policy, tol):
+    """Row T1 (alternative fusion stack): forward vs the golden made from the reference class, forward+backward vs the oracle."""
+    runtime.set_precision(policy)
+    te = cf.fill_module_(TransformerEncoder(768, num_layers=1)).eval()
+    sd = {"t." + k: v.detach().clone().requires_grad_(True) for k, v in te.state_dict().items()}
+    te.cuda()
+    x = cf.tensor_for("te_x", (2, 11, 768), kind="bias") * 20
+    m = torch.zeros(2, 1, 1, 11)
+    m[..., 8:] = O.FP16_MIN
+    xg = x.cuda().requires_grad_(True)
+    y = te(xg, m.cuda())
+    if policy == "fp32":
+        assert rel(y, GOLD["transformer_encoder_early0_y"]) < 1e-3
+    xo = x.clone().requires_grad_(True)
+    yo = O.transformer_encoder(sd, "t", xo, m, 1, 12, False)
+    assert rel(y, yo) < tol
+    w = cf.tensor_for("te_w", (2, 11, 768), kind="bias")
+    (y * w.cuda()).sum().backward()
+    (yo * w).sum().backward()
+    assert rel(xg.grad, xo.grad) < tol
+    gmax = max(v.grad.abs().max().item() for v in sd.values())
+    for k, p in te.named_parameters():          # error relative to the tensor's own scale, floored by 1e-3 of the largest gradient
+        og = sd["t." + k].grad
+        assert (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax) < 5 * tol, k
+    # training mode: dropout active (the reference never .eval()s this module), deterministic per seed, different across calls
+    te.train()
+    a, b = te(xg.detach(), m.cuda()), te(xg.detach(), m.cuda())
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
