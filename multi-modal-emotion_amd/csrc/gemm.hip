@@ -141,23 +141,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
             for (int tm = 0; tm < TM; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
     }
 
-    // epilogue: lane holds C[m = .. + i][n = .. + 4g + r], r = 0..3
+    // ---- epilogue.  Lane (g,i) holds C[m = .. + i][n = .. + 4g + r]: storing from that layout gives 32-B row segments and
+    // uncoalesced residual reads.  Instead the f32 accumulator tile goes through the (now idle) staging LDS -- one ds_write_b128
+    // per 16x16 tile, 16-B chunks XOR-swizzled with the row so both the writes and the row-major reads are conflict free -- and
+    // the epilogue runs row-major: 32 threads per row, 16 B per thread, every global access a full 512-B (f32) / 256-B (bf16) run.
+    __syncthreads();                                       // all waves finished reading the operand images
+    float* sC = reinterpret_cast<float*>(smem);            // [BM][128] f32 = BM*512 B  (<= staging size for TM = 2,3,4)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = wm * 16 * TM + tm * 16 + i;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int ch = wn * 16 + tn * 4 + g;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4)) = acc[tn][tm];
+        }
+    }
+    __syncthreads();
     const long coff = zb * p.c_zb + zg * p.c_zg;
     TO* C = reinterpret_cast<TO*>(p.C) + coff;
     TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
     const T* Gin = p.gelu_in ? reinterpret_cast<const T*>(p.gelu_in) + coff : nullptr;
     const float* R = p.resid ? p.resid + coff : nullptr;
-    const float* bias = p.bias ? p.bias + zg * p.bias_zg : nullptr;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + wm * 16 * TM + tm * 16 + i;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wn * 64 + tn * 16 + 4 * g;
-            if (n >= p.N) continue;
-            f32x4 v = acc[tn][tm] * p.alpha;
-            if (bias) v += ld4(bias + n);
+    const int ch = tid & 31, rr = tid >> 5;                // this thread's 16-B column chunk (fixed) and row within a pass
+    const int n = n0 + 4 * ch;
+    if (n < p.N) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
+#pragma unroll 4
+        for (int r = rr; r < BM; r += 8) {
+            const int m = m0 + r;
+            if (m >= p.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4));
+            v = v * p.alpha + bv;
             if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
             if (p.act == 1) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
             if (Gin) {
