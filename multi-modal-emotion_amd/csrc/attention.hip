@@ -30,6 +30,9 @@ struct AttnP {
     float scale;
 };
 
+// v_exp_f32 directly (exp2f() adds denormal-range fix-up code; scores are <= 0 after the max subtraction, flush is fine)
+TAV_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <typename T> struct HD {
     static constexpr int ES = ET<T>::ES;
     static constexpr int ROWB = 64 * ES;            // bytes per head row
@@ -86,7 +89,7 @@ TAV_DEV void row_frags_gload(uint4* f, const char* base, long ld_bytes, int r, i
 
 // ================================================================================================= forward
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
@@ -108,7 +111,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q0 + 16 * qt + i, S, g);
 
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    // softmax runs in the exp2 domain: t = s*scale*log2(e) + mask*log2(e); p = exp2(t - m).  The row sums l come out of the MFMA
+    // pipe (a ones-row operand times P^T) instead of 32 VALU adds + shuffles per tile: the kernel is VALU-issue bound.
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = p.scale * LOG2E;
+    const uint4 ones = (ES == 2) ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)
+                                 : make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
+    float m_run[2] = {-1e30f, -1e30f};
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // every register = sum_key P[key][q] (rows of the ones operand)
     f32x4 oacc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { oacc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             const int key = t * BKV + tid;
             const bool ok = key < S;
             const float mv = (MODE != 0 && ok) ? maskb[key] : 0.f;
-            r_kadd = ok ? (MODE == 1 ? mv : 0.f) : -INFINITY;
+            r_kadd = ok ? (MODE == 1 ? mv * 1.4426950408889634f : 0.f) : -INFINITY;   // already in the exp2 domain
             r_cm = (MODE == 2) ? mv : 0.f;
         }
     };
@@ -159,34 +169,41 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
                 mma16<T>(a, qf[0][s], sacc[kt][0]);
                 mma16<T>(a, qf[1][s], sacc[kt][1]);
             }
-        // scale + key additive (mask / validity), running max per query (= per lane i, both q tiles)
+        // t = s*c2 + key additive (mask / validity); running max per query (= per lane i, both q tiles)
         float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                sacc[kt][qt] = sacc[kt][qt] * p.scale + ka;
-                mx[qt] = fmaxf(mx[qt], fmaxf(fmaxf(sacc[kt][qt][0], sacc[kt][qt][1]), fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                sacc[kt][qt] = sacc[kt][qt] * c2 + ka;
+                mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
             }
         }
+        float alpha[2];
+        bool moved = false;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
             const float m_new = fmaxf(m_run[qt], mx[qt]);
-            const float alpha = __expf(m_run[qt] - m_new);
+            alpha[qt] = fast_exp2(m_run[qt] - m_new);
+            moved |= m_new > m_run[qt];
             m_run[qt] = m_new;
-            float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __expf(sacc[kt][qt][r] - m_new); sacc[kt][qt][r] = e; rs += e; }
-            l_run[qt] = l_run[qt] * alpha + rs;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+                for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] - m_new);
         }
-        // O^T += V^T P^T
+        if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                lacc[qt] *= alpha[qt];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha[qt];
+            }
+        }
+        // O^T += V^T P^T ;  l += 1^T P^T
 #pragma unroll
         for (int ks = 0; ks < BKV / KSTEP; ++ks) {
             uint4 pb[2];
@@ -197,6 +214,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
                 tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
                 pb[qt] = acc_to_kfrag<T>(tl);
             }
+            mma16<T>(ones, pb[0], lacc[0]);
+            mma16<T>(ones, pb[1], lacc[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const uint4 a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
@@ -228,9 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = lacc[qt][0];          // the MFMA already summed over all keys (all lane groups)
         const int q = q0 + 16 * qt + i;
         if (q < S) {
             const float inv = 1.f / l;
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
                 }
                 st4(orow + 16 * dt + 4 * g, v);
             }
-            if (g == 0) p.lse[((long)b * p.nh + head) * S + q] = m_run[qt] + __logf(l);
+            if (g == 0) p.lse[((long)b * p.nh + head) * S + q] = (m_run[qt] + log2f(l)) * 0.6931471805599453f;   // natural-log LSE
         }
     }
 }
@@ -270,7 +287,7 @@ __global__ void attn_bwd_delta_kernel(const AttnP p) {
 
 // ================================================================================================= backward: dK, dV
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = 32;
     constexpr int NCH = BQ * H::ROWCH / 256;
@@ -299,9 +316,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
         row_frags_gload<T>(vf[kt], Vb, p.ld_v * ES, key, S, g);
         const bool ok = key < S;
         const float mv = (MODE != 0 && ok) ? p.mask[(long)b * S + key] : 0.f;
-        kadd[kt] = ok ? (MODE == 1 ? mv : 0.f) : -INFINITY;
+        kadd[kt] = ok ? (MODE == 1 ? mv * 1.4426950408889634f : 0.f) : -INFINITY;    // exp2 domain
         cmk[kt] = (MODE == 2) ? mv : 0.f;
     }
+    const float c2 = p.scale * 1.4426950408889634f;
     f32x4 dVt[4][2], dKt[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
         tile_gload<T, BQ, true>(rdo, dOb, p.ld_do * ES, t * BQ, S, tid);
         if (tid < BQ) {
             const int q = t * BQ + tid;
-            r_lse = q < S ? lseb[q] : 0.f;
+            r_lse = q < S ? lseb[q] * 1.4426950408889634f : INFINITY;    // exp2 domain; +inf => p = 0 for rows past S
             r_delta = q < S ? deltab[q] : 0.f;
         }
     };
@@ -367,13 +385,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
             const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
             const f32x4 D = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool qok = (qbase + 16 * qt + 4 * g + r) < S;
+            for (int kt = 0; kt < 2; ++kt) {
+                // p = exp2(s*c2 + kadd - lse2);  dS (without the softmax scale, applied once to dK at the end) = p * (dP - delta)
+                const f32x4 pr4 = sacc[qt][kt] * c2 + (kadd[kt] - L);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const float pr = qok ? __expf(sacc[qt][kt][r] * p.scale + kadd[kt] - L[r]) : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = fast_exp2(pr4[r]);
                     sacc[qt][kt][r] = pr;
-                    dpacc[qt][kt][r] = pr * (dpacc[qt][kt][r] - D[r]) * p.scale;
+                    dpacc[qt][kt][r] = pr * (dpacc[qt][kt][r] - D[r]);
                 }
             }
         }
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
                 f32x4 dvv = dVt[dt][kt];
                 if (MODE == 2) dvv += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g) * cmk[kt];
                 st4(dvrow + 16 * dt + 4 * g, dvv);
-                st4(dkrow + 16 * dt + 4 * g, dKt[dt][kt]);
+                st4(dkrow + 16 * dt + 4 * g, dKt[dt][kt] * p.scale);
             }
         }
     }
@@ -433,7 +452,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnP p) {
 
 // ================================================================================================= backward: dQ
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
@@ -459,9 +478,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
         row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q, S, g);
         row_frags_gload<T>(dof[qt], dOb, p.ld_do * ES, q, S, g);
         if (q >= S) q = S - 1;
-        lse_q[qt] = p.lse[((long)b * p.nh + head) * S + q];
+        lse_q[qt] = p.lse[((long)b * p.nh + head) * S + q] * 1.4426950408889634f;     // exp2 domain
         delta_q[qt] = p.delta[((long)b * p.nh + head) * S + q];
     }
+    const float c2 = p.scale * 1.4426950408889634f;
     f32x4 dQt[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { dQt[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dQt[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
         if (tid < BKV) {
             const int key = t * BKV + tid;
             const bool ok = key < S;
-            r_kadd = ok ? (MODE == 1 ? maskb[key] : 0.f) : -INFINITY;
+            r_kadd = ok ? (MODE == 1 ? maskb[key] * 1.4426950408889634f : 0.f) : -INFINITY;
         }
     };
     auto lstore = [&](int buf) {
@@ -519,8 +539,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = __expf(sacc[kt][qt][r] * p.scale + ka[r] - lse_q[qt]);
-                    sacc[kt][qt][r] = pr * (dpacc[kt][qt][r] - delta_q[qt]) * p.scale;   // dS^T
+                    const float pr = fast_exp2(sacc[kt][qt][r] * c2 + (ka[r] - lse_q[qt]));
+                    sacc[kt][qt][r] = pr * (dpacc[kt][qt][r] - delta_q[qt]);              // dS^T without the softmax scale (applied at the store)
                 }
         }
 #pragma unroll
@@ -548,7 +568,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
         if (q < S) {
             T* dqrow = reinterpret_cast<T*>(p.dq) + ((long)b * S + q) * p.ld_dq + head * 64;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) st4(dqrow + 16 * dt + 4 * g, dQt[dt][qt]);
+            for (int dt = 0; dt < 4; ++dt) st4(dqrow + 16 * dt + 4 * g, dQt[dt][qt] * p.scale);
         }
     }
 }

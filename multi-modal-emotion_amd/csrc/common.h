@@ -32,7 +32,13 @@ TAV_DEV uint32_t f32_to_bf16_bits(float f) {
     __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return (uint32_t)__builtin_bit_cast(uint16_t, b);
 }
-TAV_DEV uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// one v_cvt_pk_bf16_f32 for the pair (converting the halves separately costs 2 cvt + shift + or)
+TAV_DEV uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 template <typename T> struct ET;
 template <> struct ET<float> {
