@@ -155,6 +155,10 @@ int tav_ln_bwd_partials(int64_t rows);
  * q/k/v weights land in one fused [3H][K] / [K][3H] operand. */
 int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int32_t dst_dtype,
                     void* stream);
+/* Multi-tensor form of tav_cast_weight: `descs` is a DEVICE array of n descriptors
+ *   { const float* src; void* dst; void* dst_t; int64 ld_dst, ld_dst_t; int32 R, C, dst_dtype, pad }   (48 bytes each)
+ * handled by one launch (grid = blocks_per_tensor x n) -- all operand copies of a transformer layer at once. */
+int tav_cast_weights_multi(const void* descs, int32_t n, int32_t blocks_per_tensor, void* stream);
 /* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst) and its dgrad form [k*ci... see DESIGN.md] */
 int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
 /* generic strided cast/copy: dst[r][c] = src[r][c] for r<R, c<C (dtypes may differ) */

@@ -69,6 +69,7 @@ _SIGS = {
     "tav_ln_bwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd_partials": (C.c_int, [i64]),
     "tav_cast_weight": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i32, vp]),
+    "tav_cast_weights_multi": (C.c_int, [vp, i32, i32, vp]),
     "tav_cast_conv_weight": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp]),
     "tav_cast2d": (C.c_int, [vp, i32, i64, vp, i32, i64, i64, i64, vp]),
     "tav_transpose2d": (C.c_int, [vp, vp, i32, i64, i64, i64, vp]),

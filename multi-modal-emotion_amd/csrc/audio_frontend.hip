@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const float* __restric
         float acc[C0_MAXK + 1];
 #pragma unroll
         for (int j = 0; j <= C0_MAXK; ++j) acc[j] = 0.f;
-        for (int tt = 0; tt < C0_BT; ++tt) {
+        const int tmax = (T_out - t0) < C0_BT ? (T_out - t0) : C0_BT;
+#pragma unroll 8
+        for (int tt = 0; tt < tmax; ++tt) {
             const int t = t0 + tt;
-            if (t >= T_out) break;
             const float d = ET<TD>::ld(dy + ((long)b * T_out + t) * C + c);
 #pragma unroll
             for (int j = 0; j < C0_MAXK; ++j) if (j < K) acc[j] += d * xs[tt * stride + j];
@@ -69,12 +70,19 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const float* __restric
         o[K] = acc[C0_MAXK];
     }
 }
-__global__ void conv0_bwd_w_final_kernel(const float* __restrict__ partial, float* dw, float* dbias, int nblocks, int C, int K, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * (K + 1)) return;
-    const int c = idx / (K + 1), j = idx - c * (K + 1);
+// 64 outputs x 4 partial groups per workgroup (the partial index is the slow axis: coalesced over outputs)
+__global__ __launch_bounds__(256) void conv0_bwd_w_final_kernel(const float* __restrict__ partial, float* dw, float* dbias, int nblocks, int C, int K,
+                                                                int accumulate) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rg = threadIdx.x >> 6, idx = blockIdx.x * 64 + l, n = C * (K + 1);
     float s = 0.f;
-    for (int k = 0; k < nblocks; ++k) s += partial[((long)k * C + c) * (K + 1) + j];
+    if (idx < n)
+        for (int k = rg; k < nblocks; k += 4) s += partial[(long)k * n + idx];
+    red[rg][l] = s;
+    __syncthreads();
+    if (rg != 0 || idx >= n) return;
+    s = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+    const int c = idx / (K + 1), j = idx - c * (K + 1);
     if (j < K) dw[c * K + j] = accumulate ? dw[c * K + j] + s : s;
     else if (dbias) dbias[c] = accumulate ? dbias[c] + s : s;
 }
@@ -123,7 +131,15 @@ __global__ __launch_bounds__(128) void wn_colsum_partial_kernel(const float* __r
     const long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block; r1 = r1 < rows ? r1 : rows;
     float s = 0.f;
-    if (k < K) for (long r = r0; r < r1; ++r) { const float av = a[r * K + k]; s += av * (bmat ? bmat[r * K + k] : av); }
+    if (k < K) {
+        if (bmat) {
+#pragma unroll 8
+            for (long r = r0; r < r1; ++r) s += a[r * K + k] * bmat[r * K + k];
+        } else {
+#pragma unroll 8
+            for (long r = r0; r < r1; ++r) { const float av = a[r * K + k]; s += av * av; }
+        }
+    }
     if (k < K) partial[(long)blockIdx.x * K + k] = s;
 }
 __global__ void wn_colsum_final_kernel(const float* __restrict__ partial, float* out, int nblocks, int K, int do_sqrt) {
@@ -197,7 +213,7 @@ extern "C" int tav_conv0_bwd_w(const float* wave, const void* dy, int32_t dt, fl
     if (dt == TAV_BF16) hipLaunchKernelGGL((conv0_bwd_w_kernel<bf16>), grid, dim3(256), 0, ST, wave, (const bf16*)dy, partials, (int)T_in, (int)T_out, (int)C, (int)K, (int)stride, nchunks);
     else if (dt == TAV_F32) hipLaunchKernelGGL((conv0_bwd_w_kernel<float>), grid, dim3(256), 0, ST, wave, (const float*)dy, partials, (int)T_in, (int)T_out, (int)C, (int)K, (int)stride, nchunks);
     else return TAV_ERR_DTYPE;
-    hipLaunchKernelGGL(conv0_bwd_w_final_kernel, G1(C * (K + 1)), partials, dw, dbias, nchunks * (int)B, (int)C, (int)K, accumulate);
+    hipLaunchKernelGGL(conv0_bwd_w_final_kernel, dim3(tav_cdiv(C * (K + 1), 64)), dim3(256), 0, ST, partials, dw, dbias, nchunks * (int)B, (int)C, (int)K, accumulate);
     return tav_last_error();
 }
 extern "C" int tav_col2im_1d(const void* dcol, void* dx, const void* pre_act, int32_t dt, int64_t B, int64_t T_in, int64_t T_out, int64_t C, int64_t K,

@@ -27,6 +27,37 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, TD* __restrict
     }
 }
 
+// Multi-tensor form: blockIdx.y selects a descriptor (one launch refreshes every operand copy of a transformer layer).
+struct CastDesc { const float* src; void* dst; void* dst_t; long ld_n, ld_t; int R, C, dtype, pad; };
+__global__ void cast_weight_multi_kernel(const CastDesc* __restrict__ descs) {
+    __shared__ float tile[32][33];
+    const CastDesc d = descs[blockIdx.y];
+    const int tiles_c = (d.C + 31) >> 5, tiles_r = (d.R + 31) >> 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {      // block-uniform loop
+        const int c0 = (t % tiles_c) * 32, r0 = (t / tiles_c) * 32;
+        for (int k = ty; k < 32; k += 8) {
+            const int r = r0 + k, c = c0 + tx;
+            float v = 0.f;
+            if (r < d.R && c < d.C) {
+                v = d.src[(long)r * d.C + c];
+                if (d.dst) { if (d.dtype == TAV_BF16) ET<bf16>::st((bf16*)d.dst + (long)r * d.ld_n + c, v); else ((float*)d.dst)[(long)r * d.ld_n + c] = v; }
+            }
+            tile[k][tx] = v;
+        }
+        __syncthreads();
+        if (d.dst_t) {
+            for (int k = ty; k < 32; k += 8) {
+                const int c = c0 + k, r = r0 + tx;
+                if (r < d.R && c < d.C) {
+                    if (d.dtype == TAV_BF16) ET<bf16>::st((bf16*)d.dst_t + (long)c * d.ld_t + r, tile[tx][k]); else ((float*)d.dst_t)[(long)c * d.ld_t + r] = tile[tx][k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // nn.Conv1d weight [co][ci][k] -> dst[co][k*CI + ci] (forward/wgrad operand) and dst_t[k*CI + ci][co] (dgrad operand)
 template <typename TD>
 __global__ void cast_conv_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, TD* __restrict__ dst_t, int CO, int CI, int K) {
@@ -397,6 +428,12 @@ extern "C" int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst
     if (dt == TAV_BF16) hipLaunchKernelGGL((cast_weight_kernel<bf16>), grid, dim3(256), 0, ST, src, (bf16*)dst, ld_n, (bf16*)dst_t, ld_t, (int)R, (int)C);
     else if (dt == TAV_F32) hipLaunchKernelGGL((cast_weight_kernel<float>), grid, dim3(256), 0, ST, src, (float*)dst, ld_n, (float*)dst_t, ld_t, (int)R, (int)C);
     else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+extern "C" int tav_cast_weights_multi(const void* descs_dev, int32_t n, int32_t blocks_per_tensor, void* stream) {
+    if (!descs_dev) return TAV_ERR_NULL;
+    if (n <= 0 || n > 65535 || blocks_per_tensor <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_weight_multi_kernel, dim3(blocks_per_tensor, n), dim3(256), 0, ST, (const CastDesc*)descs_dev);
     return tav_last_error();
 }
 extern "C" int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dt, void* stream) {

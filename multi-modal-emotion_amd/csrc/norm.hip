@@ -115,18 +115,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
 }
 
 // one workgroup per 64 columns: 4 row-groups x 64 columns, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W,
-                                                              int accumulate) {
-    __shared__ float red[4][64][2];
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W,
+                                                               int accumulate) {
+    __shared__ float red[16][64][2];
     const int l = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
     float g = 0.f, b = 0.f;
     if (c < W)
-        for (int k = rg; k < nblocks; k += 4) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
+        for (int k = rg; k < nblocks; k += 16) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
     red[rg][l][0] = g; red[rg][l][1] = b;
     __syncthreads();
     if (rg == 0 && c < W) {
-        g = red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0];
-        b = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
+        g = 0.f; b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { g += red[k][l][0]; b += red[k][l][1]; }
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     float a0 = 0.f, a1 = 0.f;
     float mean = 0.f, rstd = 0.f, gam = 0.f, bet = 0.f;
     if (BWD) { mean = stats[((long)b * C + c) * 2]; rstd = stats[((long)b * C + c) * 2 + 1]; gam = gamma[c]; bet = beta[c]; }
+#pragma unroll 4
     for (int t = t0 + rg; t < t1; t += 4) {
         const float v = ET<T>::ld(x + ((long)b * Tn + t) * C + c);
         if (!BWD) { a0 += v; a1 += v * v; }
@@ -186,7 +188,8 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
                                     const float* __restrict__ stats, long n4, int Tn, int C) {
     const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 >= n4) return;
-    const long e = i4 * 4; const int c = (int)(e % C); const long bt = e / C; const int b = (int)(bt / Tn);
+    const int C4 = C >> 2, row = (int)(i4 / C4), c = ((int)i4 - row * C4) * 4, b = row / Tn;     // 32-bit index math
+    const long e = i4 * 4;
     f32x4 v = ld4(x + e);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -200,7 +203,8 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict
                                     const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ sums, long n4, int Tn, int C) {
     const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 >= n4) return;
-    const long e = i4 * 4; const int c = (int)(e % C); const long bt = e / C; const int b = (int)(bt / Tn);
+    const int C4 = C >> 2, row = (int)(i4 / C4), c = ((int)i4 - row * C4) * 4, b = row / Tn;
+    const long e = i4 * 4;
     const f32x4 xv = ld4(x + e), dyv = ld4(dy + e);
     f32x4 o;
     const float invT = 1.f / Tn;
@@ -297,7 +301,7 @@ extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
     int e = (int)hipGetLastError();
     if (e) return e;
     if (p.partials) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 64)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 64)), dim3(1024), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
                            a->accumulate_params);
         e = (int)hipGetLastError();
     }

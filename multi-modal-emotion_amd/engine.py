@@ -72,6 +72,42 @@ class WeightCache:
             return n, t, bias
         return self._get(("qkv", id(wq)), (wq, wk, wv, bq, bk, bv), build)
 
+    def layer(self, wq, wk, wv, bq, bk, bv, wo, w1, w2):
+        """All GEMM operands of one transformer layer, refreshed by ONE multi-tensor launch when any of them changed:
+        -> (Wqkv [3H,K], Wqkv^T [K,3H], bias_qkv [3H] f32, Wo, Wo^T, W1, W1^T, W2, W2^T).  Buffers and the device descriptor
+        table are created once (parameter storage is stable), so the refresh is graph-capturable and allocation free."""
+        key = ("layer", id(wq))
+        params = (wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        ver = (_EPOCH[0],) + tuple(p._version for p in params if p is not None)
+        e = self.d.get(key)
+        if e is not None and e[0] == ver:
+            return e[1]
+        with torch.no_grad():
+            if e is None:
+                H, K = wq.shape
+                dev, lp = wq.device, self.pol.lp
+                n = torch.empty(3 * H, K, dtype=lp, device=dev)
+                t = torch.empty(K, 3 * H, dtype=lp, device=dev)
+                bias = ops.zeros_f32((3 * H,), dev)
+                ents = []
+                for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                    ents.append((w.detach(), n[j * H:(j + 1) * H], t[:, j * H:(j + 1) * H]))
+                    if b is not None:
+                        ents.append((b.detach().view(1, H), bias[j * H:(j + 1) * H].view(1, H), None))
+                outs = [n, t, bias]
+                for w in (wo, w1, w2):
+                    wn_ = torch.empty(w.shape, dtype=lp, device=dev)
+                    wt_ = torch.empty(w.shape[1], w.shape[0], dtype=lp, device=dev)
+                    ents.append((w.detach(), wn_, wt_))
+                    outs += [wn_, wt_]
+                descs = ops.make_cast_descs(ents, dev)
+                val, aux = tuple(outs), (descs, len(ents))
+            else:
+                val, aux = e[1], e[2]
+            ops.cast_weights_multi(aux[0], aux[1])
+        self.d[key] = (ver, val, aux)
+        return val
+
     def conv(self, w):
         """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], dgrad operand [k*ci, co])."""
         return self._get(("conv", id(w)), (w,), lambda: ops.cast_conv_weight(w.detach(), self.pol.lp))
@@ -135,10 +171,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        wqkv, _, bqkv = cache.qkv(wq, wk, wv, bq, bk, bv)
-        wo_n, _ = cache.linear(wo)
-        w1_n, _ = cache.linear(w1)
-        w2_n, _ = cache.linear(w2)
+        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
         x = _c(x)
         if spec.pre_ln:
             _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
@@ -162,6 +195,7 @@ class EncoderLayerFn(torch.autograd.Function):
             x2, x2_lp, mean_o, rstd_o = _ln_fwd(pol, y2, ln2_w, ln2_b, spec.eps, need_f32=True)
             mean2, rstd2 = mean_o, rstd_o
         ctx.ectx, ctx.spec = ectx, spec
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for the non-differentiable lp by-product
         ctx.has = [p is not None for p in params]
         corr, o_soft = aux
         ctx.save_for_backward(x if spec.pre_ln else None, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2 if not spec.pre_ln else None,
@@ -179,10 +213,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[17:]
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        _, wqkv_t, _ = cache.qkv(wq, wk, wv, bq, bk, bv)
-        _, wo_t = cache.linear(wo)
-        _, w1_t = cache.linear(w1)
-        _, w2_t = cache.linear(w2)
+        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
         g2 = _c(g2)
         if spec.pre_ln:
             dy2, dy2_lp = g2, _to_lp(pol, g2)
@@ -268,6 +299,7 @@ class LayerNormF32Fn(torch.autograd.Function):
         x = _c(x)
         y32, ylp, mean, rstd = _ln_fwd(ectx.pol, x, w, b, eps, need_f32=True)
         ctx.ectx = ectx
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w, b, mean, rstd)
         if ectx.pol.f32:
             ylp = y32.new_empty(0)
@@ -339,6 +371,7 @@ class TextEmbedFn(torch.autograd.Function):
         y32, ylp, pre, pos_ids, mean, rstd = ops.text_embed_fwd(ids, word.detach(), pos.detach(), typ.detach(), ln_w.detach(), ln_b.detach(), eps,
                                                                 pad_id, want_f32=True, lp_dtype=None if pol.f32 else pol.lp)
         ctx.ectx = ectx
+        ctx.set_materialize_grads(False)
         ctx.shapes = (word.shape[0], pos.shape[0], typ.shape[0])
         ctx.save_for_backward(ids, pos_ids, pre, mean, rstd, ln_w, ln_b)
         if ylp is None:

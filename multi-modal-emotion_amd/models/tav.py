@@ -56,7 +56,7 @@ class PreFormer(nn.Module):
         return input_lengths
 
     def _get_feature_vector_attention_mask(self, feature_vector_length, attention_mask, add_adapter=None):
-        non_padded = attention_mask.cumsum(dim=-1)[:, -1]
+        non_padded = attention_mask.sum(dim=-1)          # == cumsum(-1)[:, -1] of the reference (:329) without a scan kernel
         out_len = self._get_feat_extract_output_lengths(non_padded).to(torch.long)
         # same result as the reference's "set index out_len-1, flip, cumsum, flip" (:337-341) without an index_put, which
         # synchronises the host and cannot be captured into a hipGraph

@@ -215,6 +215,22 @@ def cast_weight(w, dtype, *, want_t=True, want_n=True, out_n=None, out_t=None):
     return n, t
 
 
+def make_cast_descs(entries, device):
+    """entries: list of (src f32 [R,C], dst|None, dst_t|None).  Returns a device uint8 tensor holding the C descriptor table."""
+    import struct
+    buf = bytearray()
+    for src, dst, dst_t in entries:
+        R, Cc = src.shape
+        ref = dst if dst is not None else dst_t
+        buf += struct.pack("<QQQqqiiii", src.data_ptr(), dst.data_ptr() if dst is not None else 0, dst_t.data_ptr() if dst_t is not None else 0,
+                           dst.stride(0) if dst is not None else Cc, dst_t.stride(0) if dst_t is not None else R, R, Cc, dt(ref), 0)
+    return torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(device)
+
+
+def cast_weights_multi(descs, n, blocks_per_tensor=96):
+    check(lib().tav_cast_weights_multi(ptr(descs), n, blocks_per_tensor, stream()), "cast_weights_multi")
+
+
 def cast_conv_weight(w, dtype):
     co, ci, k = w.shape
     n = torch.empty(co, k * ci, dtype=dtype, device=w.device)
