@@ -8,7 +8,7 @@
 namespace tav {
 
 constexpr int C0_TT = 32;      // output steps per workgroup (conv0 forward)
-constexpr int C0_BT = 256;     // output steps per workgroup (conv0 weight gradient)
+constexpr int C0_BT = 64;      // output steps per workgroup (conv0 weight gradient): short chunks => ~2000 workgroups, the loop is latency bound
 constexpr int C0_MAXK = 16;
 
 // y[b][t][c] = sum_j x[b][s*t + j] * w[c][j] + bias[c];  thread owns channels {tid, tid+256, ...}
@@ -105,7 +105,7 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, co
     }
     if (pre) {
         const f32x4 u = ld4(pre + e);
-        a[0] *= gelu_grad_f(u[0]); a[1] *= gelu_grad_f(u[1]); a[2] *= gelu_grad_f(u[2]); a[3] *= gelu_grad_f(u[3]);
+        a[0] *= gelu_grad_t<T>(u[0]); a[1] *= gelu_grad_t<T>(u[1]); a[2] *= gelu_grad_t<T>(u[2]); a[3] *= gelu_grad_t<T>(u[3]);
     }
     st4(dx + e, a);
 }

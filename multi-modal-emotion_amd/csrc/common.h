@@ -162,4 +162,21 @@ TAV_DEV float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// bf16 operand paths: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16's 2^-9) -- ~12 VALU instructions instead of
+// erff()'s ~35, and gelu' reuses the same exponential.  The fp32 policy keeps the exact erff forms above (parity runs).
+TAV_DEV void gelu_parts_fast(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);             // exp(-x^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+}
+template <typename T> TAV_DEV float gelu_t(float x);
+template <> TAV_DEV float gelu_t<float>(float x) { return gelu_f(x); }
+template <> TAV_DEV float gelu_t<bf16>(float x) { float c, e; gelu_parts_fast(x, c, e); return x * c; }
+template <typename T> TAV_DEV float gelu_grad_t(float x);
+template <> TAV_DEV float gelu_grad_t<float>(float x) { return gelu_grad_f(x); }
+template <> TAV_DEV float gelu_grad_t<bf16>(float x) { float c, e; gelu_parts_fast(x, c, e); return c + x * e * 0.39894228040143267794f; }
+
 }  // namespace tav

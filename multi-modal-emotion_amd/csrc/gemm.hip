@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
             f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4));
             v = v * p.alpha + bv;
             if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
-            if (p.act == 1) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
+            if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
             if (Gin) {
                 f32x4 u = ld4(Gin + (long)m * p.ld_gelu + n);
-                v[0] *= gelu_grad_f(u[0]); v[1] *= gelu_grad_f(u[1]); v[2] *= gelu_grad_f(u[2]); v[3] *= gelu_grad_f(u[3]);
+                v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
             }
             if (R) v += ld4(R + (long)m * p.ld_resid + n);
             if (p.accumulate) v += ld4(C + (long)m * p.ldc + n);

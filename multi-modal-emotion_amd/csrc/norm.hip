@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
             const int c = lane + 64 * j;
             if (c < nv) {
                 f32x4 y = (v[j] - mean) * rstd * ld4(p.gamma + 4 * c) + ld4(p.beta + 4 * c);
-                if (p.act == 1) { y[0] = gelu_f(y[0]); y[1] = gelu_f(y[1]); y[2] = gelu_f(y[2]); y[3] = gelu_f(y[3]); }
+                if (p.act == 1) { y[0] = gelu_t<TL>(y[0]); y[1] = gelu_t<TL>(y[1]); y[2] = gelu_t<TL>(y[2]); y[3] = gelu_t<TL>(y[3]); }
                 if (p.y_f32) st4(p.y_f32 + row * p.ld_y + 4 * c, y);
                 if (p.y_lp) st4(reinterpret_cast<TL*>(p.y_lp) + row * p.ld_y + 4 * c, y);
             }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
                 const f32x4 gam = ld4(p.gamma + 4 * c);
                 if (p.act == 1) {
                     const f32x4 z = xh[j] * gam + ld4(p.beta + 4 * c);
-                    d[0] *= gelu_grad_f(z[0]); d[1] *= gelu_grad_f(z[1]); d[2] *= gelu_grad_f(z[2]); d[3] *= gelu_grad_f(z[3]);
+                    d[0] *= gelu_grad_t<TL>(z[0]); d[1] *= gelu_grad_t<TL>(z[1]); d[2] *= gelu_grad_t<TL>(z[2]); d[3] *= gelu_grad_t<TL>(z[3]);
                 }
                 dg[j] += d * xh[j];
                 db[j] += d;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         if (!BWD) { a0 += v; a1 += v * v; }
         else {
             const float xh = (v - mean) * rstd;
-            const float dz = ET<T>::ld(dy + ((long)b * Tn + t) * C + c) * gelu_grad_f(xh * gam + bet);
+            const float dz = ET<T>::ld(dy + ((long)b * Tn + t) * C + c) * gelu_grad_t<T>(xh * gam + bet);
             a0 += dz; a1 += dz * xh;
         }
     }
@@ -194,7 +194,7 @@ __global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float* st = stats + ((long)b * C + c + k) * 2;
-        v[k] = gelu_f((v[k] - st[0]) * st[1] * gamma[c + k] + beta[c + k]);
+        v[k] = gelu_t<T>((v[k] - st[0]) * st[1] * gamma[c + k] + beta[c + k]);
     }
     st4(y + e, v);
 }
@@ -213,7 +213,7 @@ __global__ void gn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict
         const float* st = stats + ((long)b * C + c + k) * 2;
         const float* sm = sums + ((long)b * C + c + k) * 2;
         const float xh = (xv[k] - st[0]) * st[1], gam = gamma[c + k];
-        const float dz = dyv[k] * gelu_grad_f(xh * gam + beta[c + k]);
+        const float dz = dyv[k] * gelu_grad_t<T>(xh * gam + beta[c + k]);
         o[k] = st[1] * gam * (dz - sm[0] * invT - xh * sm[1] * invT);
     }
     st4(dx + e, o);
@@ -231,7 +231,7 @@ template <typename T> __global__ void gelu_fwd_kernel(const T* __restrict__ x, T
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     f32x4 v = ld4(x + 4 * i);
-    v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
+    v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]);
     st4(y + 4 * i, v);
 }
 template <typename T> __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n4) {
@@ -239,7 +239,7 @@ template <typename T> __global__ void gelu_bwd_kernel(const T* __restrict__ x, c
     if (i >= n4) return;
     const f32x4 v = ld4(x + 4 * i);
     f32x4 d = ld4(dy + 4 * i);
-    d[0] *= gelu_grad_f(v[0]); d[1] *= gelu_grad_f(v[1]); d[2] *= gelu_grad_f(v[2]); d[3] *= gelu_grad_f(v[3]);
+    d[0] *= gelu_grad_t<T>(v[0]); d[1] *= gelu_grad_t<T>(v[1]); d[2] *= gelu_grad_t<T>(v[2]); d[3] *= gelu_grad_t<T>(v[3]);
     st4(dx + 4 * i, d);
 }
 

@@ -100,11 +100,11 @@ class WeightCache:
                     wt_ = torch.empty(w.shape[1], w.shape[0], dtype=lp, device=dev)
                     ents.append((w.detach(), wn_, wt_))
                     outs += [wn_, wt_]
-                descs = ops.make_cast_descs(ents, dev)
-                val, aux = tuple(outs), (descs, len(ents))
+                descs, tiles = ops.make_cast_descs(ents, dev)
+                val, aux = tuple(outs), (descs, len(ents), tiles)
             else:
                 val, aux = e[1], e[2]
-            ops.cast_weights_multi(aux[0], aux[1])
+            ops.cast_weights_multi(aux[0], aux[1], aux[2])       # one workgroup per 32x32 tile of the largest tensor
         self.d[key] = (ver, val, aux)
         return val
 
