@@ -14,6 +14,7 @@
 // ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group) are bank-conflict free.
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 #include "tavhip_internal.h"
 
 namespace tav {
@@ -45,7 +46,7 @@ TAV_DEV int xcd_remap(int id, int total) {
 // the tile count divides well over the 256 CUs (e.g. M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle
 // in the last round, 732 tiles of 96 rows do not) and small-M problems still produce enough workgroups.
 template <typename T, typename TO, int TM>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
     constexpr int BM = 32 * TM, BN = 128;
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes per K-tile image
@@ -91,12 +92,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     }
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 8 * TM * 128);
     const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 32 * 128);
-    auto stage = [&](int kt, int buf) {
-        const long ko = (long)kt * 128;
-#pragma unroll
-        for (int j = 0; j < TM; ++j) glds16(ga[j] + ko, ldsA + buf * TILE_A + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(gb[j] + ko, ldsB + buf * TILE_B + j * 1024);
+    auto stage_piece = [&](int pc, long ko, int buf) {      // piece pc of the next K-tile image: TM pieces of A, then 4 of B
+        if (pc < TM) glds16(ga[pc] + ko, ldsA + buf * TILE_A + pc * 1024);
+        else glds16(gb[pc - TM] + ko, ldsB + buf * TILE_B + (pc - TM) * 1024);
     };
 
     f32x4 acc[4][TM];  // [tn][tm]
@@ -115,14 +113,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         for (int t = 0; t < 4; ++t) { const int r = wn * 64 + t * 16 + i; off_b[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
     }
     uint4 fa0[TM], fb0[4], fa1[TM], fb1[4];
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-tile: wait for the image, read both fragment sets, then the MFMAs.  The TM+4 DMA pieces of the NEXT image are
+    // issued between the MFMA groups of the first fragment set (a DMA costs the issuing wave 60-180 cycles of issue time;
+    // spread out they run under the matrix pipe, and the second set's MFMAs give them time to land before the next wait).
+    auto ktile = [&](int kt, auto prefetch) {
         const int cur = kt & 1;
         wait_vmcnt0();                                      // this wave's DMA of tile kt has landed ...
         __syncthreads();                                    // ... and everybody's; buffer cur^1 is no longer being read
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);            // overlaps the MFMAs below
         const char* cA = sA + cur * TILE_A;
         const char* cB = sB + cur * TILE_B;
+        const long ko = (long)(kt + 1) * 128;
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
 #pragma unroll
@@ -131,15 +131,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         for (int t = 0; t < TM; ++t) fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
+        __builtin_amdgcn_sched_barrier(0);                  // keep all 16 fragment reads in flight ahead of the MFMAs
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) mma16<T>(fb0[tn], fa0[tm], acc[tn][tm]);
+            if constexpr (decltype(prefetch)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pc = tn * (TM + 4) / 4; pc < (tn + 1) * (TM + 4) / 4; ++pc) stage_piece(pc, ko, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
-    }
+    };
+#pragma unroll
+    for (int pc = 0; pc < TM + 4; ++pc) stage_piece(pc, 0, 0);
+    for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
+    ktile(nk - 1, std::false_type{});
 
     // ---- epilogue.  Lane (g,i) holds C[m = .. + i][n = .. + 4g + r]: storing from that layout gives 32-B row segments and
     // uncoalesced residual reads.  Instead the f32 accumulator tile goes through the (now idle) staging LDS -- one ds_write_b128
