@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtavhip.so")
+LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
 TAV_F32, TAV_BF16 = 0, 1
 ABI_VERSION = 1

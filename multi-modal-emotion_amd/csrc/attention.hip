@@ -19,6 +19,15 @@
 #include "common.h"
 #include "tavhip_internal.h"
 
+// A/B switches (tools/ab_build.sh): issue all LDS fragment reads of a tile ahead of its first MFMA
+#ifndef TAV_HOIST_FWD
+#define TAV_HOIST_FWD 1
+#endif
+// (the same hoisting in the two backward kernels measured -1 %: not built)
+#ifndef TAV_DKDV_BQ
+#define TAV_DKDV_BQ 64       // bf16 query-tile height of the dK/dV kernel (32 or 64)
+#endif
+
 namespace tav {
 
 struct AttnP {
@@ -39,25 +48,75 @@ template <typename T> struct HD {
     static constexpr int ROWCH = ROWB / 16;         // 16-byte chunks per row (8 / 16)
     static constexpr int NSD = ROWCH / 4;           // mma16 steps over d (2 / 4)
     static constexpr int PITCH_N = ROWB + (ES == 2 ? 32 : 16);   // natural image pitch (k-strided reads conflict-free)
-    // row image: chunk index XOR-swizzled so ds_read_b128 of (16 rows x 1 chunk) per lane group is conflict-free
+    // row image: 16-B chunk index XOR-swizzled with the row.
+    //  bf16 (128-B rows): chunk ^ (((row >> 1) & 3) << 1).  ONE image serves both kinds of read, conflict free:
+    //    * ds_read_b128 of a 16x16x32 operand (lane group = 8 rows at chunk c + 8 rows at chunk c+1): the 16 slots
+    //      8*(row&1) + (chunk ^ sw) are all distinct;
+    //    * ds_read_b64_tr_b16 (a 32-lane half = 8 consecutive rows x 32 B): the XOR moves the row's chunk PAIR (bits 1-2),
+    //      so the 8 rows fall into 8 distinct 32-B bank windows and the two chunks of a pair stay in order.
+    //  f32 (256-B rows): chunk ^ (row & 15) for the row reads; k-strided reads use a second, padded natural image.
+    static constexpr bool DUAL = (ES == 2);
     static TAV_DEV int row_off(int row, int chunk) {
-        return row * ROWB + ((chunk ^ (ES == 2 ? ((row >> 1) & 7) : (row & 15))) << 4);
+        return row * ROWB + ((chunk ^ (ES == 2 ? (((row >> 1) & 3) << 1) : (row & 15))) << 4);
     }
 };
 
-// Stage ROWS x 64 elements of one head (rows row0.., clamped/zero-filled past S) into registers.
-template <typename T, int ROWS, bool ZERO_PAD>
-TAV_DEV void tile_gload(uint4* regs, const char* base, long ld_bytes, int row0, int S, int tid) {
-    constexpr int ROWCH = HD<T>::ROWCH, N = ROWS * ROWCH / 256;
+// k-strided (transposed) operand fragment straight from the swizzled bf16 ROW image: same k-set as frag_kstrided<bf16>
+// (rows krow0 + 4g + q and +16), columns 16*dt + 4p .. +3.  EXEC must be all ones.
+TAV_DEV uint4 frag_tr_rowimg(const char* img, int krow0, int dt, int lane) {
+    using H = HD<bf16>;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r0 = krow0 + 4 * g + q, r1 = r0 + 16;
+    const uint2 lo = lds_read_tr16(img + H::row_off(r0, 2 * dt + (p >> 1)) + 8 * (p & 1));
+    const uint2 hi = lds_read_tr16(img + H::row_off(r1, 2 * dt + (p >> 1)) + 8 * (p & 1));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// one element of a staged head row (row image if DUAL, natural image otherwise)
+template <typename T> TAV_DEV float tile_elem(const char* rowimg, const char* natimg, int row, int d) {
+    if constexpr (HD<T>::DUAL) return ET<T>::ld(reinterpret_cast<const T*>(rowimg + HD<T>::row_off(row, d >> 3)) + (d & 7));
+    else return ET<T>::ld(reinterpret_cast<const T*>(natimg + row * HD<T>::PITCH_N) + d);
+}
+template <typename T> TAV_DEV uint4 tile_kfrag(const char* rowimg, const char* natimg, int krow0, int dt, int lane) {
+    if constexpr (HD<T>::DUAL) return frag_tr_rowimg(rowimg, krow0, dt, lane);
+    else return frag_kstrided<T>(natimg, HD<T>::PITCH_N, krow0, 16 * dt, lane);
+}
+
+// Per-thread addressing of the streamed ROWS x 64 tiles of one (batch, head) slice: the byte offset of each of the thread's
+// 16-B chunks in tile 0 and its clamp (the same chunk of row S-1) are computed once; a tile costs one add and one min per
+// chunk (instead of a 64-bit multiply-add chain), and the load takes the slice base as a scalar operand.
+template <typename T, int ROWS, int N>
+TAV_DEV void tile_addr_init(unsigned (&off0)[N], unsigned (&offmax)[N], long ld_bytes, int S, int tid) {
+    constexpr int ROWCH = HD<T>::ROWCH;
+    static_assert(N == ROWS * ROWCH / 256, "chunks per thread");
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         const int idx = tid + 256 * e, row = idx / ROWCH, ch = idx - row * ROWCH;
-        int r = row0 + row;
-        const bool ok = r < S;
-        if (!ok) r = S - 1;
-        uint4 v = *reinterpret_cast<const uint4*>(base + (long)r * ld_bytes + ch * 16);
-        if (ZERO_PAD && !ok) v = make_uint4(0, 0, 0, 0);
-        regs[e] = v;
+        off0[e] = (unsigned)(row * ld_bytes + ch * 16);
+        offmax[e] = (unsigned)((S - 1) * ld_bytes + ch * 16);
+    }
+}
+template <int N>
+TAV_DEV void tile_gload(uint4 (&regs)[N], const char* base, const unsigned (&off0)[N], const unsigned (&offmax)[N], unsigned tile_off) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {                       // tile_off = t * ROWS * ld_bytes (wave-uniform)
+        unsigned o = off0[e] + tile_off;
+        o = o < offmax[e] ? o : offmax[e];
+        // loaded as a native vector: a plain uint4 struct copy becomes a global->private memcpy that keeps `regs` in scratch
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + o);
+        regs[e] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+// zero the staged rows past S -- applied when the tile is written to LDS, NOT at the load (a select on a just-loaded value
+// would make the wave wait for its own prefetch)
+template <typename T, int ROWS>
+TAV_DEV void tile_zero_pad(uint4* regs, int row0, int S, int tid) {
+    constexpr int ROWCH = HD<T>::ROWCH, N = ROWS * ROWCH / 256;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int idx = tid + 256 * e, row = idx / ROWCH;
+        if (row0 + row >= S) regs[e] = make_uint4(0, 0, 0, 0);
     }
 }
 template <typename T, int ROWS>
@@ -126,28 +185,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 
     const int nkt = (S + BKV - 1) / BKV;
     uint4 rk[NCH], rv[NCH];
-    float r_kadd = 0.f, r_cm = 0.f;
+    float r_mask = 0.f;
+    // gload only ISSUES loads (no arithmetic on a loaded value: that would put a vmcnt wait -- a drain of the whole prefetch --
+    // right behind the issue); lstore, one tile of compute later, turns the raw mask value into the per-key additive terms.
+    unsigned k_off0[NCH], k_max[NCH], v_off0[NCH], v_max[NCH];
+    tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
+    tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    const unsigned kstep_b = (unsigned)(BKV * p.ld_k * ES), vstep_b = (unsigned)(BKV * p.ld_v * ES);
     auto gload = [&](int t) {
-        tile_gload<T, BKV, false>(rk, Kb, p.ld_k * ES, t * BKV, S, tid);
-        tile_gload<T, BKV, false>(rv, Vb, p.ld_v * ES, t * BKV, S, tid);
-        if (tid < BKV) {
-            const int key = t * BKV + tid;
-            const bool ok = key < S;
-            const float mv = (MODE != 0 && ok) ? maskb[key] : 0.f;
-            r_kadd = ok ? (MODE == 1 ? mv * 1.4426950408889634f : 0.f) : -INFINITY;   // already in the exp2 domain
-            r_cm = (MODE == 2) ? mv : 0.f;
+        tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
+        tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        if (MODE != 0 && tid < BKV) {
+            int key = t * BKV + tid;
+            key = key < S ? key : S - 1;
+            r_mask = maskb[key];
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
         tile_lstore_row<T, BKV>(rk, base, tid);
         tile_lstore_nat<T, BKV>(rv, base + KROW_B, tid);
         if (tid < BKV) {
+            const bool ok = t * BKV + tid < S;
             float* f = reinterpret_cast<float*>(base + KROW_B + VNAT_B);
-            f[tid] = r_kadd; f[BKV + tid] = r_cm;
+            f[tid] = ok ? (MODE == 1 ? r_mask * 1.4426950408889634f : 0.f) : -INFINITY;   // already in the exp2 domain
+            f[BKV + tid] = (MODE == 2 && ok) ? r_mask : 0.f;
         }
     };
-    gload(0); lstore(0);
+    gload(0); lstore(0, 0);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) settle(qf[qt][s]);
     __syncthreads();
 
     for (int t = 0; t < nkt; ++t) {
@@ -161,39 +230,82 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         f32x4 sacc[4][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) { sacc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sacc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // bf16: every LDS read of the tile (8 K-row + 16 transposed V fragments, 64 VGPRs) is issued up front, so the V
+        // fragments arrive under the QK^T MFMAs and the softmax instead of costing an exposed LDS round trip per PV group.
+        constexpr int NKS = BKV / KSTEP;
+        constexpr bool HOIST = (ES == 2) && TAV_HOIST_FWD;
+        uint4 kfr[HOIST ? 4 : 1][HOIST ? NSD : 1], vfr[HOIST ? NKS : 1][HOIST ? 4 : 1];
+        if constexpr (HOIST) {
 #pragma unroll
-        for (int s = 0; s < NSD; ++s)
+            for (int s = 0; s < NSD; ++s)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const uint4 a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
-                mma16<T>(a, qf[0][s], sacc[kt][0]);
-                mma16<T>(a, qf[1][s], sacc[kt][1]);
-            }
-        // t = s*c2 + key additive (mask / validity); running max per query (= per lane i, both q tiles)
-        float mx[2] = {-INFINITY, -INFINITY};
+                for (int kt = 0; kt < 4; ++kt) kfr[kt][s] = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                sacc[kt][qt] = sacc[kt][qt] * c2 + ka;
-                mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
-            }
+                for (int dt = 0; dt < 4; ++dt) vfr[ks][dt] = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NSD; ++s)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    mma16<T>(kfr[kt][s], qf[0][s], sacc[kt][0]);
+                    mma16<T>(kfr[kt][s], qf[1][s], sacc[kt][1]);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSD; ++s)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
+                    mma16<T>(a, qf[0][s], sacc[kt][0]);
+                    mma16<T>(a, qf[1][s], sacc[kt][1]);
+                }
         }
+        // running max per query (= per lane i, both q tiles), then p = exp2(s*c2 + kadd - m).  The per-key additive term is zero
+        // except under a pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S): only those tiles pay for it;
+        // the others take the max over the raw scores and fold scale and max into one fma per element.
         float alpha[2];
         bool moved = false;
+        const bool with_kadd = (MODE == 1) || (t == nkt - 1);
+        if (with_kadd) {
+            float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
-            mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx[qt]);
-            alpha[qt] = fast_exp2(m_run[qt] - m_new);
-            moved |= m_new > m_run[qt];
-            m_run[qt] = m_new;
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int qt = 0; qt < 2; ++qt) {
+                    sacc[kt][qt] = sacc[kt][qt] * c2 + ka;
+                    mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                }
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] - m_new);
+            for (int qt = 0; qt < 2; ++qt) {
+                const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx[qt]));
+                alpha[qt] = fast_exp2(m_run[qt] - m_new);
+                moved |= m_new > m_run[qt];
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] - m_new);
+            }
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+                for (int kt = 1; kt < 4; ++kt)
+                    mx = fmaxf(fmaxf(mx, sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx) * c2);
+                alpha[qt] = fast_exp2(m_run[qt] - m_new);
+                moved |= m_new > m_run[qt];
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(__builtin_fmaf(sacc[kt][qt][r], c2, -m_new));
+            }
         }
         if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
 #pragma unroll
@@ -205,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         }
         // O^T += V^T P^T ;  l += 1^T P^T
 #pragma unroll
-        for (int ks = 0; ks < BKV / KSTEP; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             uint4 pb[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
@@ -218,7 +330,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
             mma16<T>(ones, pb[1], lacc[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                uint4 a;
+                if constexpr (HOIST) a = vfr[ks][dt];
+                else a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
                 mma16<T>(a, pb[0], oacc[dt][0]);
                 mma16<T>(a, pb[1], oacc[dt][1]);
             }
@@ -231,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
                 corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
             }
         }
-        if (t + 1 < nkt) lstore(cur ^ 1);
+        if (t + 1 < nkt) lstore(t + 1, cur ^ 1);
         __syncthreads();
     }
 
@@ -286,13 +400,17 @@ __global__ void attn_bwd_delta_kernel(const AttnP p) {
 }
 
 // ================================================================================================= backward: dK, dV
+// query-tile height of the dK/dV kernel: 64 for bf16 (half as many barriers and staging round trips per MFMA as 32), 32 for
+// f32 (register budget)
+template <typename T> constexpr int dkdv_bq() { return sizeof(T) == 2 ? TAV_DKDV_BQ : 32; }
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
     using H = HD<T>;
-    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = 32;
+    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T>(), NQT = BQ / 16;
     constexpr int NCH = BQ * H::ROWCH / 256;
-    constexpr int ROW_B = BQ * H::ROWB, NAT_B = BQ * H::PITCH_N;
-    constexpr int BUF_B = 2 * ROW_B + 2 * NAT_B + 2 * BQ * 4;   // Qrow, dOrow, Qnat, dOnat, lse, delta
+    constexpr int ROW_B = BQ * H::ROWB, NAT_B = H::DUAL ? 0 : BQ * H::PITCH_N;
+    constexpr int BUF_B = 2 * ROW_B + 2 * NAT_B + 2 * BQ * 4;   // Qrow, dOrow, [Qnat, dOnat: f32 only], lse, delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 2 * BUF_B);   // [4][64] + [64]
 
@@ -319,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
         kadd[kt] = ok ? (MODE == 1 ? mv * 1.4426950408889634f : 0.f) : -INFINITY;    // exp2 domain
         cmk[kt] = (MODE == 2) ? mv : 0.f;
     }
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.scale * 1.4426950408889634f, inv_scale = 1.0f / p.scale;
     f32x4 dVt[4][2], dKt[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -327,30 +445,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
         for (int c = 0; c < 2; ++c) { dVt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dKt[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float dosum_part = 0.f;
 
+    const bool with_kadd = (MODE == 1) || (k0 + 32 > S);      // wave-uniform
     const int nqt = (S + BQ - 1) / BQ;
     uint4 rq[NCH], rdo[NCH];
     float r_lse = 0.f, r_delta = 0.f;
+    unsigned q_off0[NCH], q_max[NCH], do_off0[NCH], do_max[NCH];
+    tile_addr_init<T, BQ>(q_off0, q_max, p.ld_q * ES, S, tid);
+    tile_addr_init<T, BQ>(do_off0, do_max, p.ld_do * ES, S, tid);
+    const unsigned qstep_b = (unsigned)(BQ * p.ld_q * ES), dostep_b = (unsigned)(BQ * p.ld_do * ES);
     auto gload = [&](int t) {
-        tile_gload<T, BQ, true>(rq, Qb, p.ld_q * ES, t * BQ, S, tid);
-        tile_gload<T, BQ, true>(rdo, dOb, p.ld_do * ES, t * BQ, S, tid);
-        if (tid < BQ) {
-            const int q = t * BQ + tid;
-            r_lse = q < S ? lseb[q] * 1.4426950408889634f : INFINITY;    // exp2 domain; +inf => p = 0 for rows past S
-            r_delta = q < S ? deltab[q] : 0.f;
+        tile_gload(rq, Qb, q_off0, q_max, t * qstep_b);
+        tile_gload(rdo, dOb, do_off0, do_max, t * dostep_b);
+        if (tid < BQ) {                                   // raw loads only (see attn_fwd_kernel::gload)
+            int q = t * BQ + tid;
+            q = q < S ? q : S - 1;
+            r_lse = lseb[q];
+            r_delta = deltab[q];
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
+        tile_zero_pad<T, BQ>(rq, t * BQ, S, tid);
+        tile_zero_pad<T, BQ>(rdo, t * BQ, S, tid);
         tile_lstore_row<T, BQ>(rq, base, tid);
         tile_lstore_row<T, BQ>(rdo, base + ROW_B, tid);
-        tile_lstore_nat<T, BQ>(rq, base + 2 * ROW_B, tid);
-        tile_lstore_nat<T, BQ>(rdo, base + 2 * ROW_B + NAT_B, tid);
+        if constexpr (!H::DUAL) {
+            tile_lstore_nat<T, BQ>(rq, base + 2 * ROW_B, tid);
+            tile_lstore_nat<T, BQ>(rdo, base + 2 * ROW_B + NAT_B, tid);
+        }
         if (tid < BQ) {
+            const bool ok = t * BQ + tid < S;
             float* f = reinterpret_cast<float*>(base + 2 * ROW_B + 2 * NAT_B);
-            f[tid] = r_lse; f[BQ + tid] = r_delta;
+            f[tid] = ok ? -r_lse * inv_scale : -INFINITY;   // S accumulators start at -lse/scale; -inf => p = 0 for rows past S
+            f[BQ + tid] = ok ? -r_delta : 0.f;                // dP accumulators start at -delta
         }
     };
-    gload(0); lstore(0);
+    gload(0); lstore(0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) { settle(kf[kt][s]); settle(vf[kt][s]); }
+        settle(kadd[kt]); settle(cmk[kt]);
+    }
     __syncthreads();
 
     for (int t = 0; t < nqt; ++t) {
@@ -364,15 +500,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
         const float* delta_s = lse_s + BQ;
         const int qbase = t * BQ;
 
-        f32x4 sacc[2][2], dpacc[2][2];   // [qt][kt]: rows(regs) = query, cols(lanes) = key
+        // Row constants as the initial accumulators: S' = q.k - lse/scale and dP' = dO.v - delta leave the MFMA chains ready, so
+        // p = exp2(c2 * S') and dS = p * dP' need no subtraction per element (the per-query constants sit on the register axis).
+        f32x4 sacc[NQT][2], dpacc[NQT][2];   // [qt][kt]: rows(regs) = query, cols(lanes) = key
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NQT; ++a) {
+            const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * a + 4 * g);
+            const f32x4 D = *reinterpret_cast<const f32x4*>(delta_s + 16 * a + 4 * g);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { sacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int c = 0; c < 2; ++c) { sacc[a][c] = L; dpacc[a][c] = D; }
+        }
+        constexpr int NKS = BQ / KSTEP;
 #pragma unroll
         for (int s = 0; s < NSD; ++s)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < NQT; ++qt) {
                 const uint4 aq = *reinterpret_cast<const uint4*>(Qrow + H::row_off(16 * qt + i, 4 * s + g));
                 const uint4 ad = *reinterpret_cast<const uint4*>(dOrow + H::row_off(16 * qt + i, 4 * s + g));
                 mma16<T>(aq, kf[0][s], sacc[qt][0]);
@@ -381,23 +523,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
                 mma16<T>(ad, vf[1][s], dpacc[qt][1]);
             }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const f32x4 L = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
-            const f32x4 D = *reinterpret_cast<const f32x4*>(delta_s + 16 * qt + 4 * g);
+        for (int qt = 0; qt < NQT; ++qt) {
+            // p = exp2(c2 * S' + kadd);  dS (without the softmax scale, applied once to dK at the end) = p * dP'.
+            // kadd is zero except under a pre-softmax mask (MODE 1) and for keys past S (-inf): wave-uniform choice.
+            if (with_kadd) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                // p = exp2(s*c2 + kadd - lse2);  dS (without the softmax scale, applied once to dK at the end) = p * (dP - delta)
-                const f32x4 pr4 = sacc[qt][kt] * c2 + (kadd[kt] - L);
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = fast_exp2(pr4[r]);
-                    sacc[qt][kt][r] = pr;
-                    dpacc[qt][kt][r] = pr * (dpacc[qt][kt][r] - D[r]);
-                }
+                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(__builtin_fmaf(sacc[qt][kt][r], c2, kadd[kt]));
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(sacc[qt][kt][r] * c2);
             }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dpacc[qt][kt][r] *= sacc[qt][kt][r];
         }
 #pragma unroll
-        for (int ks = 0; ks < BQ / KSTEP; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             uint4 pb[2], dsb[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
@@ -409,10 +555,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 a1 = frag_kstrided<T>(dOnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                const uint4 a1 = tile_kfrag<T>(dOrow, dOnat, ks * KSTEP, dt, lane);
                 mma16<T>(a1, pb[0], dVt[dt][0]);
                 mma16<T>(a1, pb[1], dVt[dt][1]);
-                const uint4 a2 = frag_kstrided<T>(Qnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                const uint4 a2 = tile_kfrag<T>(Qrow, Qnat, ks * KSTEP, dt, lane);
                 mma16<T>(a2, dsb[0], dKt[dt][0]);
                 mma16<T>(a2, dsb[1], dKt[dt][1]);
             }
@@ -420,10 +566,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
         if (MODE == 2) {   // sum_q dO[q][d]  (rows past S were zero-filled)
             const int d = tid & 63, rq8 = tid >> 6;
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
-                dosum_part += ET<T>::ld(reinterpret_cast<const T*>(dOnat + (rq8 * 8 + rr) * H::PITCH_N) + d);
+            for (int rr = 0; rr < BQ / 4; ++rr)
+                dosum_part += tile_elem<T>(dOrow, dOnat, rq8 * (BQ / 4) + rr, d);
         }
-        if (t + 1 < nqt) lstore(cur ^ 1);
+        if (t + 1 < nqt) lstore(t + 1, cur ^ 1);
         __syncthreads();
     }
 
@@ -456,8 +602,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
-    constexpr int ROW_B = BKV * H::ROWB, NAT_B = BKV * H::PITCH_N;
-    constexpr int BUF_B = 2 * ROW_B + NAT_B + BKV * 4;   // Krow, Vrow, Knat, kadd
+    constexpr int ROW_B = BKV * H::ROWB, NAT_B = H::DUAL ? 0 : BKV * H::PITCH_N;
+    constexpr int BUF_B = 2 * ROW_B + NAT_B + BKV * 4;   // Krow, Vrow, [Knat: f32 only], kadd
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
@@ -478,8 +624,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
         row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q, S, g);
         row_frags_gload<T>(dof[qt], dOb, p.ld_do * ES, q, S, g);
         if (q >= S) q = S - 1;
-        lse_q[qt] = p.lse[((long)b * p.nh + head) * S + q] * 1.4426950408889634f;     // exp2 domain
-        delta_q[qt] = p.delta[((long)b * p.nh + head) * S + q];
+        lse_q[qt] = -p.lse[((long)b * p.nh + head) * S + q] / p.scale;      // S accumulators start at -lse/scale, dP at -delta
+        delta_q[qt] = -p.delta[((long)b * p.nh + head) * S + q];           // (row constants as the initial accumulators)
     }
     const float c2 = p.scale * 1.4426950408889634f;
     f32x4 dQt[4][2];
@@ -489,23 +635,34 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     const int nkt = (S + BKV - 1) / BKV;
     uint4 rk[NCH], rv[NCH];
     float r_kadd = 0.f;
+    unsigned k_off0[NCH], k_max[NCH], v_off0[NCH], v_max[NCH];
+    tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
+    tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    const unsigned kstep_b = (unsigned)(BKV * p.ld_k * ES), vstep_b = (unsigned)(BKV * p.ld_v * ES);
     auto gload = [&](int t) {
-        tile_gload<T, BKV, false>(rk, Kb, p.ld_k * ES, t * BKV, S, tid);
-        tile_gload<T, BKV, false>(rv, Vb, p.ld_v * ES, t * BKV, S, tid);
-        if (tid < BKV) {
-            const int key = t * BKV + tid;
-            const bool ok = key < S;
-            r_kadd = ok ? (MODE == 1 ? maskb[key] * 1.4426950408889634f : 0.f) : -INFINITY;
+        tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
+        tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        if (MODE == 1 && tid < BKV) {                     // raw load only (see attn_fwd_kernel::gload)
+            int key = t * BKV + tid;
+            key = key < S ? key : S - 1;
+            r_kadd = maskb[key];
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
         tile_lstore_row<T, BKV>(rk, base, tid);
         tile_lstore_row<T, BKV>(rv, base + ROW_B, tid);
-        tile_lstore_nat<T, BKV>(rk, base + 2 * ROW_B, tid);
-        if (tid < BKV) reinterpret_cast<float*>(base + 2 * ROW_B + NAT_B)[tid] = r_kadd;
+        if constexpr (!H::DUAL) tile_lstore_nat<T, BKV>(rk, base + 2 * ROW_B, tid);
+        if (tid < BKV)
+            reinterpret_cast<float*>(base + 2 * ROW_B + NAT_B)[tid] = (t * BKV + tid < S) ? (MODE == 1 ? r_kadd * 1.4426950408889634f : 0.f) : -INFINITY;
     };
-    gload(0); lstore(0);
+    gload(0); lstore(0, 0);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) { settle(qf[qt][s]); settle(dof[qt][s]); }
+        settle(lse_q[qt]); settle(delta_q[qt]);
+    }
     __syncthreads();
 
     for (int t = 0; t < nkt; ++t) {
@@ -520,7 +677,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { sacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dpacc[kt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int c = 0; c < 2; ++c) {
+                sacc[kt][c] = f32x4{lse_q[c], lse_q[c], lse_q[c], lse_q[c]};
+                dpacc[kt][c] = f32x4{delta_q[c], delta_q[c], delta_q[c], delta_q[c]};
+            }
+        constexpr int NKS = BKV / KSTEP;
 #pragma unroll
         for (int s = 0; s < NSD; ++s)
 #pragma unroll
@@ -532,19 +693,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
                 mma16<T>(av, dof[0][s], dpacc[kt][0]);
                 mma16<T>(av, dof[1][s], dpacc[kt][1]);
             }
+        // p = exp2(c2 * S' + kadd);  dS^T (without the softmax scale, applied at the store) = p * dP'.  kadd is zero except under a
+        // pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S).
+        if ((MODE == 1) || (t == nkt - 1)) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = fast_exp2(sacc[kt][qt][r] * c2 + (ka[r] - lse_q[qt]));
-                    sacc[kt][qt][r] = pr * (dpacc[kt][qt][r] - delta_q[qt]);              // dS^T without the softmax scale (applied at the store)
-                }
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(__builtin_fmaf(sacc[kt][qt][r], c2, ka[r])) * dpacc[kt][qt][r];
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] * c2) * dpacc[kt][qt][r];
         }
 #pragma unroll
-        for (int ks = 0; ks < BKV / KSTEP; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             uint4 dsb[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
@@ -554,12 +723,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 a = frag_kstrided<T>(Knat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                const uint4 a = tile_kfrag<T>(Krow, Knat, ks * KSTEP, dt, lane);
                 mma16<T>(a, dsb[0], dQt[dt][0]);
                 mma16<T>(a, dsb[1], dQt[dt][1]);
             }
         }
-        if (t + 1 < nkt) lstore(cur ^ 1);
+        if (t + 1 < nkt) lstore(t + 1, cur ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -577,9 +746,9 @@ template <typename T> constexpr size_t fwd_lds() {
     return 2 * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
 }
 template <typename T> constexpr size_t dkdv_lds() {
-    return 2 * (2 * 32 * HD<T>::ROWB + 2 * 32 * HD<T>::PITCH_N + 2 * 32 * 4) + (256 + 64) * 4;
+    return 2 * (2 * dkdv_bq<T>() * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * dkdv_bq<T>() * HD<T>::PITCH_N) + 2 * dkdv_bq<T>() * 4) + (256 + 64) * 4;
 }
-template <typename T> constexpr size_t dq_lds() { return 2 * (2 * 64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 64 * 4); }
+template <typename T> constexpr size_t dq_lds() { return 2 * (2 * 64 * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 64 * HD<T>::PITCH_N) + 64 * 4); }
 
 static int check(const tav_attn_args* a, bool bwd) {
     if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse) return TAV_ERR_NULL;

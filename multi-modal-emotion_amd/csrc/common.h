@@ -140,6 +140,12 @@ TAV_DEV void glds16(const void* gsrc, unsigned lds_base) {
                  : "v"(gsrc), "s"(lds_base)
                  : "memory");
 }
+// Values loaded from global memory BEFORE a loop and consumed inside it: hipcc's waitcnt pass cannot tell how many younger loads
+// a conditional in-loop prefetch has put in flight, so it protects every in-loop use with `s_waitcnt vmcnt(0/1)` -- which drains
+// the prefetch issued a few instructions earlier and exposes the full memory latency on every tile.  settle() makes the register
+// the output of an (empty) asm statement: the wait happens once, here, and the loop body carries none.
+TAV_DEV void settle(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+TAV_DEV void settle(float& v) { asm volatile("" : "+v"(v)); }
 TAV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- wave reductions ----------------------------------------------------------------------------
@@ -152,6 +158,18 @@ TAV_DEV float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// max over the four lanes {i, i+16, i+32, i+48} (the 4 row groups of a 16x16 accumulator column) without an LDS round trip:
+// v_permlane16_swap / v_permlane32_swap exchange rows between two copies of the value (gfx950), one v_max each.
+TAV_DEV float vmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TAV_DEV float max_over_row_groups(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float a = vmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(a);
+    auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return vmax_raw(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
 }
 
 // exact-erf GELU (nn.GELU() default; reference utils/TAVFormer.py:398) and its derivative

@@ -1,0 +1,65 @@
+"""Focused, low-noise timings for A/B of two builds on ONE box (TAV_LIB selects the library; see tools/ab_build.sh).
+usage: python tools/gpu_ab.py [attn] [gemm] [tn]   -- prints min / median over 7 repetitions of 50 launches each."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import torch  # noqa: E402
+
+import tav_amd.ops as ops  # noqa: E402
+
+dev = "cuda"
+what = set(sys.argv[1:]) or {"attn", "gemm", "tn"}
+B = int(os.environ.get("TAV_B", "8"))
+
+
+def timeit(fn, iters=50, reps=7):
+    for _ in range(5):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2]
+
+
+def rnd(*s, dtype=torch.bfloat16):
+    return torch.randn(*s, device=dev).to(dtype)
+
+
+tag = os.path.basename(os.environ.get("TAV_LIB", "libtavhip.so"))
+if "attn" in what:
+    for (name, S, mode) in [("video", 1464, 0), ("fusion", 481, 2), ("audio", 249, 0), ("text", 128, 1)]:
+        nh, H = 12, 768
+        qkv = rnd(B * S, 3 * H)
+        mask = torch.zeros(B, S, device=dev) if mode else None
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        lo, med = timeit(lambda: ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode))
+        fl = 4 * B * nh * S * S * 64
+        print(f"[{tag}] attn_fwd {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+        o, lse, aux = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode)
+        do = rnd(B * S, H)
+        lo, med = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, aux if mode == 2 else None, B, S, nh, key_mask=mask, mask_mode=mode))
+        print(f"[{tag}] attn_bwd {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2.5 * fl / lo / 1e6:7.1f} TF")
+if "gemm" in what:
+    for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
+                            ("video ffn2", B * 1464, 768, 3072), ("fusion qkv", B * 481, 2304, 768), ("audio ffn1", B * 249, 3072, 768),
+                            ("conv1", B * 7999, 512, 1536), ("square 4096", 4096, 4096, 4096)]:
+        a, b = rnd(M, K), rnd(N, K)
+        bias = torch.randn(N, device=dev)
+        lo, med = timeit(lambda: ops.gemm_nt(a, b, bias=bias))
+        print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N * K / lo / 1e6:7.1f} TF")
+if "tn" in what:
+    for (name, M, N1, N2) in [("video dWqkv", B * 1464, 2304, 768), ("video dWo", B * 1464, 768, 768), ("video dW1", B * 1464, 3072, 768),
+                              ("video dW2", B * 1464, 768, 3072), ("text dW1", B * 128, 3072, 768)]:
+        a, b = rnd(M, N1), rnd(M, N2)
+        lo, med = timeit(lambda: ops.gemm_tn(a, b))
+        print(f"[{tag}] gemm_tn {name:12s} M={M:6d} N1={N1:5d} N2={N2:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N1 * N2 / lo / 1e6:7.1f} TF")
