@@ -146,6 +146,15 @@ TAV_DEV void glds16(const void* gsrc, unsigned lds_base) {
 // the output of an (empty) asm statement: the wait happens once, here, and the loop body carries none.
 TAV_DEV void settle(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 TAV_DEV void settle(float& v) { asm volatile("" : "+v"(v)); }
+// Same, with the source split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the per-K-tile
+// address update is then ONE v_add_u32 per instruction instead of a 64-bit multiply-add chain.
+TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_base)
+                 : "memory");
+}
 TAV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- wave reductions ----------------------------------------------------------------------------
