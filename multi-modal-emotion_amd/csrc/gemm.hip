@@ -42,17 +42,31 @@ TAV_DEV int xcd_remap(int id, int total) {
     return base + k;
 }
 
-// TM = 16-row MFMA tiles per wave along M (2, 3 or 4): the workgroup tile is (32*TM) x 128.  The host picks TM per launch so that
-// the tile count divides well over the 256 CUs (e.g. M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle
-// in the last round, 732 tiles of 96 rows do not) and small-M problems still produce enough workgroups.
-template <typename T, typename TO, int TM>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
+// ablation switches for tools/ab_build.sh (timing experiments only; results are wrong with any of them set)
+#ifdef TAV_ABL_NOMFMA
+#define TAV_NT_MMA(b, a, c) do { (c)[0] += __uint_as_float((b).x ^ (a).x); } while (0)
+#else
+#define TAV_NT_MMA(b, a, c) mma16<T>(b, a, c)
+#endif
+
+// TM = 16-row MFMA tiles per wave along M (2, 3 or 4); NW = waves per workgroup (4 or 8), arranged (NW/2) x 2, each wave a
+// (16*TM) x 64 block: the workgroup tile is (8*TM*NW) x 128 = 64/96/128 x 128 (NW = 4) or 256 x 128 (NW = 8, TM = 4).
+// The host picks the shape per launch:
+//  * the kernel is bound by what one CU can pull from L2 into LDS (~70-90 GB/s per CU measured: 4096^3 tops out at 1.15 PF
+//    with 128x128 tiles = 64 FLOP per staged byte, and a deeper ring at equal occupancy changes nothing), so the 256x128 tile
+//    (85 FLOP/B, one 8-wave workgroup per CU) is faster wherever its coarser tile grid still fills the chip;
+//  * the tile count must divide well over the 256 CUs (M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle in
+//    the last round, 732 tiles of 96 rows do not) and small-M problems must still produce enough workgroups.
+template <typename T, typename TO, int TM, int NST, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
-    constexpr int BM = 32 * TM, BN = 128;
+    constexpr int BM = 8 * TM * NW, BN = 128;
+    constexpr int PB = 16 / NW;                           // DMA pieces of the B image per wave (the A image: TM per wave)
+    constexpr int NP = TM + PB;                           // DMA pieces per wave per K-tile
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes per K-tile image
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                  // [2][BM][128B]  activations (m)
-    char* sB = smem + 2 * TILE_A;     // [2][BN][128B]  weights (n)
+    char* sA = smem;                  // [NST][BM][128B]  activations (m)
+    char* sB = smem + NST * TILE_A;   // [NST][BN][128B]  weights (n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -74,11 +88,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction fills 64 consecutive 16-B slots = 8 rows x 8 chunk
     // slots of the image; the LDS side is linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE
-    // chunk each lane fetches.  Wave w stages rows [8*TM*w, +8*TM) of A and [32w, +32) of B.
+    // chunk each lane fetches.  Wave w stages rows [8*TM*w, +8*TM) of A and [8*PB*w, +8*PB) of B.
     const int lr = lane >> 3, lc = lane & 7;
     // per-lane 32-bit byte offsets from the wave-uniform operand bases (the host checks M*lda and N*ldb fit): advancing a
     // K-tile is one v_add_u32 per DMA instruction
-    unsigned ga[TM], gb[4];
+    unsigned ga[TM], gb[PB];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int r = wave * 8 * TM + j * 8 + lr;
@@ -86,14 +100,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         ga[j] = (unsigned)((long)ra * p.lda * ES + swz(r, lc) * 16);     // slot lc of row r holds chunk lc ^ f(r)
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wave * 32 + j * 8 + lr;
+    for (int j = 0; j < PB; ++j) {
+        const int r = wave * 8 * PB + j * 8 + lr;
         int rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
         gb[j] = (unsigned)((long)rb * p.ldb * ES + swz(r, lc) * 16);
     }
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 8 * TM * 128);
-    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 32 * 128);
-    auto stage_piece = [&](int pc, unsigned ko, int buf) {  // piece pc of the next K-tile image: TM pieces of A, then 4 of B
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 8 * PB * 128);
+    auto stage_piece = [&](int pc, unsigned ko, int buf) {  // piece pc of the next K-tile image: TM pieces of A, then PB of B
         if (pc < TM) glds16_s(Ab, ga[pc] + ko, ldsA + buf * TILE_A + pc * 1024);
         else glds16_s(Bb, gb[pc - TM] + ko, ldsB + buf * TILE_B + (pc - TM) * 1024);
     };
@@ -117,13 +131,23 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // One K-tile: wait for the image, read both fragment sets, then the MFMAs.  The TM+4 DMA pieces of the NEXT image are
     // issued between the MFMA groups of the first fragment set (a DMA costs the issuing wave 60-180 cycles of issue time;
     // spread out they run under the matrix pipe, and the second set's MFMAs give them time to land before the next wait).
-    auto ktile = [&](int kt, auto prefetch) {
-        const int cur = kt & 1;
-        wait_vmcnt0();                                      // this wave's DMA of tile kt has landed ...
-        __syncthreads();                                    // ... and everybody's; buffer cur^1 is no longer being read
+    // NST-deep ring: while tile kt is multiplied, tiles kt+1 .. kt+NST-2 are in flight and tile kt+NST-1 is being issued, so a
+    // DMA has NST-1 tile times to land (an L2 hit takes longer than one 128x128x64 tile's MFMAs).  vmcnt counts in issue
+    // order: tile kt has landed once at most (NST-2) younger tiles x NP pieces are outstanding.
+    auto ktile = [&](int kt, int cur, auto prefetch) {
+        if constexpr (decltype(prefetch)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");
+        else wait_vmcnt0();                                 // tail: fewer tiles in flight than the constant assumes
+#ifndef TAV_ABL_NOBAR
+        __syncthreads();                                    // everybody's pieces landed; the buffer refilled below is no longer read
+#endif
         const char* cA = sA + cur * TILE_A;
         const char* cB = sB + cur * TILE_B;
-        const unsigned ko = (unsigned)(kt + 1) * 128u;
+        const unsigned ko = (unsigned)(kt + NST - 1) * 128u;
+        const int nxt = (cur + NST - 1) % NST;
+#ifdef TAV_ABL_NOLDS
+        if (kt == 0)
+#endif
+        {
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
 #pragma unroll
@@ -132,27 +156,39 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int t = 0; t < TM; ++t) fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
+        }
         __builtin_amdgcn_sched_barrier(0);                  // keep all 16 fragment reads in flight ahead of the MFMAs
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) mma16<T>(fb0[tn], fa0[tm], acc[tn][tm]);
+            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
             if constexpr (decltype(prefetch)::value) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pc = tn * (TM + 4) / 4; pc < (tn + 1) * (TM + 4) / 4; ++pc) stage_piece(pc, ko, cur ^ 1);
+                for (int pc = tn * NP / 4; pc < (tn + 1) * NP / 4; ++pc) {
+#ifdef TAV_ABL_NODMA
+                    if (kt < 0)
+#endif
+                    stage_piece(pc, ko, nxt);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) mma16<T>(fb1[tn], fa1[tm], acc[tn][tm]);
+            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
     };
 #pragma unroll
-    for (int pc = 0; pc < TM + 4; ++pc) stage_piece(pc, 0, 0);
-    for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
-    ktile(nk - 1, std::false_type{});
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) stage_piece(pc, (unsigned)t * 128u, t);
+        }
+    int cur = 0;
+    int kt = 0;
+    for (; kt + NST - 1 < nk; ++kt) { ktile(kt, cur, std::true_type{}); cur = cur + 1 == NST ? 0 : cur + 1; }
+    for (; kt < nk; ++kt) { ktile(kt, cur, std::false_type{}); cur = cur + 1 == NST ? 0 : cur + 1; }
 
     // ---- epilogue.  Lane (g,i) holds C[m = .. + i][n = .. + 4g + r]: storing from that layout gives 32-B row segments and
     // uncoalesced residual reads.  Instead the f32 accumulator tile goes through the (now idle) staging LDS -- one ds_write_b128
@@ -175,13 +211,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
     const T* Gin = p.gelu_in ? reinterpret_cast<const T*>(p.gelu_in) + coff : nullptr;
     const float* R = p.resid ? p.resid + coff : nullptr;
-    const int ch = tid & 31, rr = tid >> 5;                // this thread's 16-B column chunk (fixed) and row within a pass
+    const int ch = tid & 31, rr = tid >> 5;                // this thread's 16-B column chunk (fixed) and row within a pass (2*NW rows)
     const int n = n0 + 4 * ch;
     if (n < p.N) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
 #pragma unroll 4
-        for (int r = rr; r < BM; r += 8) {
+        for (int r = rr; r < BM; r += 2 * NW) {
             const int m = m0 + r;
             if (m >= p.M) break;
             f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4));
@@ -452,6 +488,19 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 
 using namespace tav;
 
+// tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
+static int nt_pick_tile(int M, int tiles_n, int nz, bool bf16_in) {
+    int tm = 4;
+    double best = 1e30;
+    for (int c = 4; c >= 2; --c) {
+        const long tiles = (long)((M + 32 * c - 1) / (32 * c)) * tiles_n * nz;
+        const double cost = (double)((tiles + 255) / 256) * (c + 0.8);
+        if (cost < best - 1e-9) { best = cost; tm = c; }
+    }
+    (void)bf16_in;
+    return tm;
+}
+
 extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!a || !a->A || !a->B || !a->C) return TAV_ERR_NULL;
@@ -476,29 +525,29 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
     p.tiles_n = (p.N + 127) / 128;
     // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-    int tm = a->tile_m_hint;
-    if (tm < 2 || tm > 4) {
-        double best = 1e30;
-        for (int c = 4; c >= 2; --c) {
-            const long tiles = (long)((p.M + 32 * c - 1) / (32 * c)) * p.tiles_n * nzb * p.nzg;
-            const double cost = (double)((tiles + 255) / 256) * (c + 0.8);
-            if (cost < best - 1e-9) { best = cost; tm = c; }
-        }
-    }
-    p.tiles_m = (p.M + 32 * tm - 1) / (32 * tm);
-    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(256);
-    const size_t lds = 2 * (32 * tm + 128) * 128;
-#define TAV_NT_LAUNCH(TT, TOO)                                                                              \
-    do {                                                                                                    \
-        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4>), grid, block, lds, stream, p);          \
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3>), grid, block, lds, stream, p);     \
-        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2>), grid, block, lds, stream, p);                  \
+    int tm = a->tile_m_hint & 15;                            // 2/3/4: 64/96/128-row tiles (4 waves); 8: 256-row tile (8 waves)
+    if (a->in_dtype != TAV_BF16 && tm == 8) tm = 4;
+    if (tm != 8 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.tiles_n, nzb * p.nzg, a->in_dtype == TAV_BF16);
+    const int bm = tm == 8 ? 256 : 32 * tm;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm == 8 ? 512 : 256);
+    // 4 waves: 2-deep ring, two workgroups per CU.  8 waves: 3-deep ring = 144 KB (one workgroup per CU; the f32 epilogue tile of
+    // 256 x 128 needs 128 KB of it)
+    const size_t lds = tm == 8 ? (size_t)3 * (256 + 128) * 128 : (size_t)2 * (bm + 128) * 128;
+#define TAV_NT_LAUNCH(TT, TOO)                                                                                 \
+    do {                                                                                                       \
+        if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8>), grid, block, lds, stream, p);       \
+        else if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 2, 4>), grid, block, lds, stream, p);  \
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, 2, 4>), grid, block, lds, stream, p);  \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, 2, 4>), grid, block, lds, stream, p);               \
     } while (0)
     if (a->in_dtype == TAV_BF16) {
         if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
         else TAV_NT_LAUNCH(bf16, float);
     } else {
-        TAV_NT_LAUNCH(float, float);
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4>), grid, block, lds, stream, p);
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4>), grid, block, lds, stream, p);
     }
 #undef TAV_NT_LAUNCH
     return (int)hipGetLastError();

@@ -63,3 +63,15 @@ if "tn" in what:
         a, b = rnd(M, N1), rnd(M, N2)
         lo, med = timeit(lambda: ops.gemm_tn(a, b))
         print(f"[{tag}] gemm_tn {name:12s} M={M:6d} N1={N1:5d} N2={N2:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N1 * N2 / lo / 1e6:7.1f} TF")
+if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/128 x 128 with 4 waves, 8 = 256 x 128 with 8 waves)
+    for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
+                            ("video ffn2", B * 1464, 768, 3072), ("video dffn1", B * 1464, 768, 3072), ("video dqkv", B * 1464, 768, 2304),
+                            ("fusion qkv", B * 481, 2304, 768), ("fusion ffn1", B * 481, 3072, 768), ("audio ffn1", B * 249, 3072, 768),
+                            ("conv1", B * 7999, 512, 1536), ("square 4096", 4096, 4096, 4096)]:
+        a, b = rnd(M, K), rnd(N, K)
+        bias = torch.randn(N, device=dev)
+        row = []
+        for tm in (0, 2, 3, 4, 8):
+            lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm), iters=30, reps=5)
+            row.append(f"tm{tm} {lo:6.1f}")
+        print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: " + "  ".join(row) + "  us")
