@@ -618,6 +618,66 @@ class TailFn(torch.autograd.Function):
         return (d_av, dpool[1], d_aud, d_vid, None, None, None, None, None, None, *dparams, dW, db)
 
 
+class HeadFn(torch.autograd.Function):
+    """dropout(p) -> Linear(K, N) on a [B, K] f32 feature matrix, N small (7): the classifier head of the single- and dual-modal
+    models (reference SingleModels/models/text.py:61-65; models/tav.py:497-499 is the same pair inside TailFn)."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, seed, w, b):
+        x = _c(x)
+        mask = None
+        if p_drop > 0.0:
+            x, mask = ops.dropout_fwd(x, p_drop, seed, 0)
+        ctx.p_drop = p_drop
+        ctx.save_for_backward(x, mask, w)
+        return ops.head_fwd(x, w.detach(), b.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mask, w = ctx.saved_tensors
+        dx, dW, db = ops.head_bwd(x, w, _c(g))
+        if mask is not None:
+            dx = ops.dropout_bwd(dx, mask, ctx.p_drop)
+        return dx, None, None, dW, db
+
+
+class PoolNormCatFn(torch.autograd.Function):
+    """cat_j LN_j(pool_j(x_j)) for a list of branches, each either already pooled [B, 768] or a sequence [B*S_j, 768] that is
+    mean-pooled over its S_j tokens first (models/tav.py:478-495 without the fusion branch)."""
+
+    @staticmethod
+    def forward(ctx, B, seq_lens, *args):
+        n = len(seq_lens)
+        xs, params = args[:n], args[n:]
+        pooled, stats, outs = [], [], []
+        for j in range(n):
+            xp = _c(xs[j]) if seq_lens[j] == 0 else ops.mean_pool_fwd(_c(xs[j]), B, seq_lens[j])
+            y, _, mean, rstd = ops.ln_fwd(xp, params[2 * j], params[2 * j + 1], 1e-5, want_f32=True)
+            pooled.append(xp)
+            stats += [mean, rstd]
+            outs.append(y)
+        ctx.geom = (B, tuple(seq_lens))
+        ctx.save_for_backward(*pooled, *stats, *params)
+        return torch.cat(outs, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, seq_lens = ctx.geom
+        n = len(seq_lens)
+        sv = ctx.saved_tensors
+        pooled, stats, params = sv[:n], sv[n:3 * n], sv[3 * n:]
+        W = pooled[0].shape[1]
+        dxs, dparams = [], []
+        for j in range(n):
+            dy = ops.cast2d(g[:, j * W:(j + 1) * W], torch.float32)
+            dx, _, dg, dbt = ops.ln_bwd(dy, pooled[j], params[2 * j], params[2 * j + 1], stats[2 * j], stats[2 * j + 1], want_f32=True)
+            if seq_lens[j]:
+                dx, _ = ops.mean_pool_bwd(dx, B, seq_lens[j])
+            dxs.append(dx)
+            dparams += [dg, dbt]
+        return (None, None, *dxs, *dparams)
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """torch.nn.CrossEntropyLoss (optionally class-weighted), mean reduction (utils/global_functions.py:63-64)."""
 

@@ -225,7 +225,7 @@ def make_cast_descs(entries, device):
         buf += struct.pack("<QQQqqiiii", src.data_ptr(), dst.data_ptr() if dst is not None else 0, dst_t.data_ptr() if dst_t is not None else 0,
                            dst.stride(0) if dst is not None else Cc, dst_t.stride(0) if dst_t is not None else R, R, Cc, dt(ref), 0)
     tiles = max(((s.shape[0] + 31) // 32) * ((s.shape[1] + 31) // 32) for s, _, _ in entries)
-    return torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(device), tiles
+    return torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone().to(device), tiles
 
 
 def cast_weights_multi(descs, n, blocks_per_tensor=96):

@@ -3,8 +3,9 @@
 import torch
 
 
-def make_batch(cfg, batch_size, *, seed=1234, s_text=128, t_audio=80000, n_visual_true=104, device="cpu"):
-    """Returns ([text, audio, visual] dicts exactly as collate_batch yields them, labels float [B])."""
+def make_batch(cfg, batch_size, *, seed=1234, s_text=128, t_audio=80000, n_visual_true=104, device="cpu", text_only=False, with_video=True):
+    """Returns ([text, audio, visual] dicts exactly as collate_batch yields them, labels float [B]).  text_only / with_video=False skip
+    the (large) modalities the single- and dual-modal entrypoints do not read (their dicts come back as None)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     tc, vc = cfg["text"], cfg["video"]
     B = batch_size
@@ -14,11 +15,18 @@ def make_batch(cfg, batch_size, *, seed=1234, s_text=128, t_audio=80000, n_visua
     if npad:
         ids[:, s_text - npad:] = tc["pad_id"]
         text_mask[:, s_text - npad:] = 0
+    if text_only:
+        labels = torch.randint(0, 7, (B,), generator=g).float()
+        return [{"input_ids": ids.to(device), "attention_mask": text_mask.to(device)}, None, None], labels.to(device)
     audio = torch.randn(B, t_audio, generator=g) * 0.1
     audio_mask = torch.ones(B, t_audio)
     cut = int(0.8 * t_audio)
     audio[0, cut:] = 0
     audio_mask[0, cut:] = 0
+    if not with_video:
+        labels = torch.randint(0, 7, (B,), generator=g).float()
+        return [{"input_ids": ids.to(device), "attention_mask": text_mask.to(device)},
+                {"audio_features": audio.to(device), "attention_mask": audio_mask.to(device)}, None], labels.to(device)
     video = torch.randn(B, vc["frames"], 3, vc["image"], vc["image"], generator=g)
     ntok = (vc["image"] // vc["patch"]) ** 2 * (vc["frames"] // vc["tubelet"])
     vmask = torch.zeros(B, ntok, dtype=torch.bool)

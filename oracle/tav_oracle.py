@@ -367,3 +367,27 @@ def tav_step(sd_model, sd_pre, cfg, batch, labels, class_weights=None, epoch=0, 
     else:
         loss = new_cross_entropy(logits, labels, epoch, epoch_switch, class_weights)
     return logits, loss
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY.md §8(f) rows 1-2
+def text_classifier_forward(sd, cfg, input_id, mask, check="val", dropout_mask=None, dropout_p=0.0):
+    """SingleModels/models/text.py:41-69 (BertClassifier.forward): pooled output -> dropout iff check == 'train' -> Linear(768, out)."""
+    _, x = text_encoder(sd, "bert", cfg["text"], input_id, mask)                                      # :58
+    if check == "train" and dropout_mask is not None:                                                 # :61-62
+        x = x * dropout_mask / (1.0 - dropout_p)
+    return _lin(sd, "linear", x)                                                                      # :65
+
+
+def text_audio_forward(sd, cfg, input_ids, text_attention_mask, audio_features, check="val", dropout_mask=None, dropout_p=0.0):
+    """Dual text+audio classifier (BASELINE config 4).  The reference file DoubleModels/models/text_audio.py does not parse
+    (SURVEY.md §8f.2), so the path is DEFINED as models/tav.py:473-499 minus the video and fusion branches:
+    logits = Linear(1536, out)(dropout(cat[LN(pooled_text), LN(mean_t(Linear(H_a,768)(wav2vec2(audio))))]))."""
+    aud = w2v2_model(sd, "wav2vec2", cfg["audio"], audio_features)                                    # tav.py:476
+    aud = torch.mean(_lin(sd, "wav_2_768_2", aud), dim=1)                                             # :478
+    _, t = text_encoder(sd, "bert", cfg["text"], input_ids, text_attention_mask)                      # :485
+    t = _ln(sd, "bert_norm", t, 1e-5)                                                                 # :486
+    aud = _ln(sd, "aud_norm", aud, 1e-5)                                                              # :489
+    ta = torch.cat([t, aud], dim=1)
+    if check == "train" and dropout_mask is not None:
+        ta = ta * dropout_mask / (1.0 - dropout_p)
+    return _lin(sd, "linear1", ta)

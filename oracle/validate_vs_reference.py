@@ -129,6 +129,42 @@ class RefTAVForMAE(torch.nn.Module):
         return self.linear1(tav)
 
 
+class RefBertClassifier(torch.nn.Module):
+    """SingleModels/models/text.py:41-69 from a local config (same attribute names => same state_dict keys)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.bert = hf_text(cfg["text"])
+        self.linear = torch.nn.Linear(768, cfg["output_dim"])
+        cf.fill_module_(self)
+        self.eval()
+
+    def forward(self, input_id, mask, check):
+        _, x = self.bert(input_ids=input_id, attention_mask=mask, return_dict=False)[:2]
+        return self.linear(x)                       # dropout only when check == "train" (:61-62)
+
+
+class RefBertAudioClassifier(torch.nn.Module):
+    """Dual text+audio path as DEFINED in SURVEY.md §8f.2 (the reference file does not parse): models/tav.py:473-499 minus the
+    video and fusion branches, composed from the HF modules the reference calls."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.bert = hf_text(cfg["text"])
+        self.bert_norm = torch.nn.LayerNorm(768)
+        self.wav2vec2 = hf_audio(cfg["audio"])
+        self.wav_2_768_2 = torch.nn.Linear(cfg["audio"]["hidden"], 768)
+        self.aud_norm = torch.nn.LayerNorm(768)
+        self.linear1 = torch.nn.Linear(768 * 2, cfg["output_dim"])
+        cf.fill_module_(self)
+        self.eval()
+
+    def forward(self, input_ids, text_attention_mask, audio_features):
+        aud = torch.mean(self.wav_2_768_2(self.wav2vec2(audio_features)[0]), dim=1)
+        t = self.bert_norm(self.bert(input_ids=input_ids, attention_mask=text_attention_mask, return_dict=False)[1])
+        return self.linear1(torch.cat([t, self.aud_norm(aud)], dim=1))
+
+
 def tiny_cfg(name):
     cfg = O.preset(name + "-tiny")
     cfg["video"] = dict(cfg["video"], image=32)        # 2x2x8 = 32 tubelet tokens: true widths, CPU-sized
@@ -240,6 +276,28 @@ def main():
         out[f"{name}_grad_fusion_q0"] = g["random_mae_encoder.layer.0.attention.attention.query.weight"].grad.numpy()[:8, :8].copy()
         gp = dict(pre.named_parameters())
         out[f"{name}_grad_pre_conv1"] = gp["wav2vec2.feature_extractor.conv_layers.1.conv.weight"].grad.numpy()[:4, :4].copy()
+
+        # ---- 4. SURVEY.md §8(f) rows 1-2: text-only classifier and text+audio dual classifier -------------------------
+        for tag, ref, fwd in (("textcls", RefBertClassifier(cfg), lambda m: m(batch["input_ids"], batch["text_mask"], "val")),
+                              ("textaudio", RefBertAudioClassifier(cfg), lambda m: m(batch["input_ids"], batch["text_mask"], batch["audio_features"]))):
+            lg = fwd(ref)
+            ls = torch.nn.functional.cross_entropy(lg, labels)
+            ls.backward()
+            gn2 = grad_norm([p for p in ref.parameters() if p.grad is not None])
+            sdr = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in ref.state_dict().items()}
+            if tag == "textcls":
+                o_lg = O.text_classifier_forward(sdr, cfg, batch["input_ids"], batch["text_mask"])
+            else:
+                o_lg = O.text_audio_forward(sdr, cfg, batch["input_ids"], batch["text_mask"], batch["audio_features"])
+            o_ls = torch.nn.functional.cross_entropy(o_lg, labels)
+            o_ls.backward()
+            o_gn2 = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sdr.values() if v.requires_grad and v.grad is not None)).item()
+            errs = dict(logits=rel(o_lg, lg), loss=abs(o_ls.item() - ls.item()) / abs(ls.item()), gradnorm=abs(o_gn2 - gn2) / gn2)
+            worst = max(worst, *errs.values())
+            print(f"preset {name} {tag}: " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()) + f"   loss {ls.item():.6f} gradnorm {gn2:.4e}")
+            out[f"{name}_{tag}_logits"] = lg.detach().numpy()
+            out[f"{name}_{tag}_loss"] = np.array([ls.item()])
+            out[f"{name}_{tag}_gradnorm"] = np.array([gn2])
 
     print(f"worst relative difference oracle vs reference-side modules: {worst:.2e}")
     if worst > 2e-4:

@@ -206,3 +206,85 @@ def test_transformer_encoder_vs_oracle_and_golden(gpu, policy, tol):
     te.train()
     a, b = te(xg.detach(), m.cuda()), te(xg.detach(), m.cuda())
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+# ---- SURVEY.md §8(f) rows 1-2 --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["textcls", "textaudio"])
+@pytest.mark.parametrize("preset", ["A", "B"])
+def test_single_and_dual_models_golden_fp32(gpu, preset, tag):
+    """Text-only classifier (reference SingleModels/models/text.py) and the text+audio dual classifier on libtavhip, fp32 policy,
+    closed-form weights: logits / loss / grad-norm against the goldens made from the HF modules the reference calls."""
+    from tav_amd.DoubleModels.models.text_audio import BertAudioClassifier
+    from tav_amd.SingleModels.models.text import BertClassifier
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset(preset + "-tiny")
+    runtime.set_precision("fp32")
+    batch, labels = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=16, image=32, vocab=cfg["text"]["vocab"], pad_id=cfg["text"]["pad_id"], nkeep_fusion=4)
+    args = dict(output_dim=7, dropout=0.5)
+    model = cf.fill_module_(BertClassifier(args, config=cfg) if tag == "textcls" else BertAudioClassifier(args, config=cfg)).cuda()
+    if tag == "textcls":
+        logits = model(batch["input_ids"], batch["text_mask"], "val")
+    else:
+        logits = model(batch["input_ids"], batch["text_mask"], batch["audio_features"], check="val")
+    loss = CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    gn = grad_norm(list(model.parameters())).item()
+    assert rel(logits.detach().cpu(), torch.as_tensor(GOLD[f"{preset}_{tag}_logits"])) < 1e-3
+    assert abs(loss.item() - GOLD[f"{preset}_{tag}_loss"][0]) / GOLD[f"{preset}_{tag}_loss"][0] < 1e-3
+    assert abs(gn - GOLD[f"{preset}_{tag}_gradnorm"][0]) / GOLD[f"{preset}_{tag}_gradnorm"][0] < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["textcls", "textaudio"])
+def test_single_and_dual_models_bf16_vs_oracle(gpu, tag):
+    """bf16 policy, seeded-random weights, 10 s audio for the dual model's long-sequence audio attention (Sa = 499
+    at T = 160000, BASELINE config 4): logits and loss within 1e-2 of the CPU oracle; dropout active under check="train"."""
+    from tav_amd.DoubleModels.models.text_audio import BertAudioClassifier
+    from tav_amd.SingleModels.models.text import BertClassifier
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset("B")
+    cfg["text"]["layers"] = 2
+    cfg["audio"]["layers"] = 2
+    runtime.set_precision("bf16")
+    args = dict(output_dim=7, dropout=0.5)
+    model = BertClassifier(args, config=cfg) if tag == "textcls" else BertAudioClassifier(args, config=cfg)
+    synthetic.seeded_init_(model, 3)
+    (tx, au, _), lab = synthetic.make_batch(cfg, 2, s_text=128, t_audio=160000 if tag == "textaudio" else 8000, n_visual_true=104)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        if tag == "textcls":
+            o_logits = O.text_classifier_forward(sd, cfg, tx["input_ids"], tx["attention_mask"])
+        else:
+            o_logits = O.text_audio_forward(sd, cfg, tx["input_ids"], tx["attention_mask"], au["audio_features"])
+        o_loss = torch.nn.functional.cross_entropy(o_logits, lab.long())
+    model.cuda()
+
+    def run(check):
+        if tag == "textcls":
+            return model(tx["input_ids"], tx["attention_mask"], check)
+        return model(tx["input_ids"], tx["attention_mask"], au["audio_features"], check=check)
+
+    logits = run("val")
+    loss = CrossEntropyLoss()(logits, lab)
+    loss.backward()
+    assert rel(logits.detach().cpu(), o_logits) < 1e-2
+    assert abs(loss.item() - o_loss.item()) / o_loss.item() < 1e-2
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 30 and all(torch.isfinite(g).all() for g in grads)
+    a, b = run("train"), run("train")
+    assert not torch.equal(a, b)
+
+
+def test_entrypoints_run_one_tiny_epoch(gpu, capsys):
+    """tav_nn.py / SingleModels/text_nn.py / DoubleModels/text_audio_nn.py mains (reference entrypoints of the same names): one epoch on
+    synthetic utterances with the tiny preset; losses must be finite."""
+    import tav_amd.tav_nn as tav_nn
+    from tav_amd.DoubleModels import text_audio_nn
+    from tav_amd.SingleModels import text_nn
+    argv = ["--preset", "B-tiny", "--epoch", "1", "--batch_size", "2", "--synthetic", "4", "--dtype", "bf16", "--loss", "CrossEntropy"]
+    try:
+        for mod in (text_nn, text_audio_nn, tav_nn):
+            mod.main(argv)
+            out = capsys.readouterr().out
+            assert "nan" not in out.lower()
+    finally:
+        C.set_default_preset("A")

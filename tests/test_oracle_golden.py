@@ -110,3 +110,31 @@ def test_preformer_and_step_golden(composed):
     assert abs(gn - GOLD[f"{name}_gradnorm"][0]) / GOLD[f"{name}_gradnorm"][0] < 1e-4
     assert rel(sdm["linear1.weight"].grad[:, :16], GOLD[f"{name}_grad_linear1"]) < 1e-3
     assert rel(sdm["random_mae_encoder.layer.0.attention.attention.query.weight"].grad[:8, :8], GOLD[f"{name}_grad_fusion_q0"]) < 2e-2
+
+
+# ---- text-only classifier, text+audio dual classifier ---------------------------------------------
+ARGS_F = dict(output_dim=7, dropout=0.5)
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+@pytest.mark.parametrize("tag", ["textcls", "textaudio"])
+def test_single_and_dual_models_golden(name, tag):
+    from tav_amd.DoubleModels.models.text_audio import BertAudioClassifier
+    from tav_amd.SingleModels.models.text import BertClassifier
+    cfg = C.preset(name + "-tiny")
+    batch, labels = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=16, image=32, vocab=cfg["text"]["vocab"], pad_id=cfg["text"]["pad_id"], nkeep_fusion=4)
+    model = cf.fill_module_(BertClassifier(ARGS_F, config=cfg) if tag == "textcls" else BertAudioClassifier(ARGS_F, config=cfg))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    if tag == "textcls":
+        assert {"linear.weight", "linear.bias"} <= set(sd) and all(k.startswith(("bert.", "linear.")) for k in sd)     # reference text.py:48-52
+        logits = O.text_classifier_forward(sd, cfg, batch["input_ids"], batch["text_mask"])
+    else:
+        assert {"bert_norm.weight", "aud_norm.weight", "wav_2_768_2.weight", "linear1.weight"} <= set(sd)            # names of models/tav.py:435-458
+        assert sd["linear1.weight"].shape == (7, 1536)
+        logits = O.text_audio_forward(sd, cfg, batch["input_ids"], batch["text_mask"], batch["audio_features"])
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.requires_grad and v.grad is not None)).item()
+    assert rel(logits.detach(), GOLD[f"{name}_{tag}_logits"]) < 1e-4
+    assert abs(loss.item() - GOLD[f"{name}_{tag}_loss"][0]) < 1e-5
+    assert abs(gn - GOLD[f"{name}_{tag}_gradnorm"][0]) / GOLD[f"{name}_{tag}_gradnorm"][0] < 1e-4
