@@ -87,6 +87,17 @@ typedef struct tav_gemm_tn_args {
 int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit);
 int tav_gemm_tn(const tav_gemm_tn_args* args, void* stream);
 
+/* Up to 4 weight gradients over the SAME token axis (rows, contiguous, one batch) in one launch, e.g. the dWqkv / dWo / dW1 / dW2 of
+ * one transformer layer (utils/TAVFormer.py:243-271 under autograd): out_k[n1][n2] = sum_t A_k[t][n1] * B_k[t][n2], and, when dbias
+ * is given, dbias_k[n1] = sum_t A_k[t][n1].  Every tile sums over all rows (no split over tokens, no workspace); results overwrite. */
+typedef struct tav_gemm_tn_problem {
+    const void* A; const void* B;   /* [rows, N1] (row stride lda), [rows, N2] (row stride ldb) */
+    float* out;                     /* [N1][N2] f32 */
+    float* dbias;                   /* optional [N1] f32 */
+    int64_t N1, N2, lda, ldb;
+} tav_gemm_tn_problem;
+int tav_gemm_tn_grouped(const tav_gemm_tn_problem* problems, int32_t nproblems, int64_t rows, int32_t dtype, void* stream);
+
 /* Column sums (bias gradients): out[n] (+)= sum_m x[m][n]; partials = workspace nparts*N f32. */
 int tav_colsum(const void* x, int32_t dtype, int64_t M, int64_t N, int64_t ld, float* partials, int32_t nparts, float* out,
                int32_t accumulate, void* stream);

@@ -34,6 +34,10 @@ class GemmTNArgs(C.Structure):
                 ("dtype", i32), ("accumulate", i32), ("scale", f32)]
 
 
+class GemmTNProblem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("out", vp), ("dbias", vp), ("N1", i64), ("N2", i64), ("lda", i64), ("ldb", i64)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("key_mask", vp), ("lse", vp), ("corr", vp), ("o_soft", vp),
                 ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp),
@@ -62,6 +66,7 @@ _SIGS = {
     "tav_gemm_nt": (C.c_int, [C.POINTER(GemmNTArgs), vp]),
     "tav_gemm_tn_splits": (C.c_int, [i64, i64, i64, i64, C.POINTER(i32), C.POINTER(i32)]),
     "tav_gemm_tn": (C.c_int, [C.POINTER(GemmTNArgs), vp]),
+    "tav_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTNProblem), i32, i64, i32, vp]),
     "tav_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp, i32, vp]),
     "tav_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), vp]),

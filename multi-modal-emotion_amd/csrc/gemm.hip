@@ -283,7 +283,7 @@ template <> TAV_DEV uint4 tn_frag<float>(const char* tile, int krow0, int col0, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     using TT = TNTile<T>;
     constexpr int ES = ET<T>::ES, PK = ET<T>::PK, KSTEP = ET<T>::KSTEP;
     constexpr int BT = 128, KT = 64;
@@ -299,14 +299,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     const int g = lane >> 4, i = lane & 15;
     const int w1 = wave >> 1, w2 = wave & 1;
 
-    const int tile = xcd_remap(blockIdx.x, p.tiles_1 * p.tiles_2);
     // consecutive tiles (same XCD, same L2) walk the SHORTER tile axis fastest: the panel of the other operand is reused at
     // once and the working set of re-read panels is min(tiles_1, tiles_2) x ~1 MB instead of the max (dW2: 24 -> 6 panels)
     int t1, t2;
     if (p.tiles_1 >= p.tiles_2) { t1 = tile / p.tiles_2; t2 = tile - t1 * p.tiles_2; }
     else { t2 = tile / p.tiles_1; t1 = tile - t2 * p.tiles_1; }
     const int n1_0 = t1 * BT, n2_0 = t2 * BT;
-    const int split = blockIdx.y;
     const int zb = split / p.chunks_per_batch, ck = split - zb * p.chunks_per_batch;
     const int row_begin = ck * p.chunk_rows;
     int row_end = row_begin + p.chunk_rows; row_end = row_end < p.rows_per_batch ? row_end : p.rows_per_batch;
@@ -423,6 +421,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
             st4(S + (long)n1 * p.N2 + n2, acc[a][b]);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+    gemm_tn_body<T>(p, xcd_remap(blockIdx.x, p.tiles_1 * p.tiles_2), blockIdx.y);
+}
+
+// Up to TN_GROUP_MAX weight gradients that share the token axis (one transformer layer: dWqkv, dWo, dW1, dW2) in ONE launch,
+// each tile summing over ALL tokens: the layer's 432 tiles fill the chip on their own, so nothing is split over tokens -- no f32
+// slabs, no reduce kernels, a quarter of the launches.  S / bias_part of each problem point at the final dW / db.
+constexpr int TN_GROUP_MAX = 4;
+struct GemmTNGroup {
+    GemmTN p[TN_GROUP_MAX];
+    int tile_end[TN_GROUP_MAX];     // prefix sums of tiles_1 * tiles_2
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const GemmTNGroup grp) {
+    const int t = xcd_remap(blockIdx.x, grp.tile_end[grp.n - 1]);
+    int g = 0;
+#pragma unroll
+    for (int k = 0; k < TN_GROUP_MAX - 1; ++k) g += (k < grp.n - 1 && t >= grp.tile_end[k]) ? 1 : 0;
+    const int first = g == 0 ? 0 : grp.tile_end[g - 1];
+    gemm_tn_body<T>(grp.p[g], t - first, 0);
 }
 
 // out[n1][perm(n2)] (+)= sum_s S[s][n1][n2];  perm(n2) = (n2 % inner) * outer + n2 / inner  (outer = 1: identity).
@@ -588,6 +610,39 @@ extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch
     *chunk_rows = (int32_t)cr;
     *nsplit = (int32_t)(cpb * nbatch);
     return 0;
+}
+
+extern "C" int tav_gemm_tn_grouped(const tav_gemm_tn_problem* probs, int32_t nprob, int64_t rows, int32_t dtype, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!probs) return TAV_ERR_NULL;
+    if (nprob <= 0 || nprob > TN_GROUP_MAX || rows <= 0) return TAV_ERR_SHAPE;
+    if (dtype != TAV_BF16 && dtype != TAV_F32) return TAV_ERR_DTYPE;
+    const int es = dtype == TAV_BF16 ? 2 : 4, pk = 16 / es;
+    GemmTNGroup grp;
+    int total = 0;
+    for (int k = 0; k < TN_GROUP_MAX; ++k) {
+        const tav_gemm_tn_problem& a = probs[k < nprob ? k : nprob - 1];
+        if (k < nprob) {
+            if (!a.A || !a.B || !a.out) return TAV_ERR_NULL;
+            if (a.N1 <= 0 || a.N2 <= 0) return TAV_ERR_SHAPE;
+            if (a.N1 % pk || a.N2 % pk || a.N2 % 4) return TAV_ERR_SHAPE;
+            if (a.lda % pk || a.ldb % pk) return TAV_ERR_ALIGN;
+            if ((rows + 64) * (a.lda > a.ldb ? a.lda : a.ldb) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
+        }
+        GemmTN& p = grp.p[k];
+        p.A = (const char*)a.A; p.B = (const char*)a.B; p.S = a.out; p.bias_part = a.dbias;
+        p.N1 = (int)a.N1; p.N2 = (int)a.N2; p.lda = a.lda; p.ldb = a.ldb;
+        p.rows_per_batch = (int)rows; p.a_zb = 0; p.b_zb = 0;
+        p.chunk_rows = (int)(((rows + 63) / 64) * 64); p.chunks_per_batch = 1;
+        p.tiles_1 = (p.N1 + 127) / 128; p.tiles_2 = (p.N2 + 127) / 128;
+        if (k < nprob) total += p.tiles_1 * p.tiles_2;
+        grp.tile_end[k] = total;
+    }
+    grp.n = nprob;
+    dim3 grid(total), block(256);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16>), grid, block, 4 * 64 * 256, stream, grp);
+    else hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), grid, block, 4 * 64 * 512, stream, grp);
+    return (int)hipGetLastError();
 }
 
 extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {

@@ -10,6 +10,8 @@ Design (MI355X-first):
     exactly the tensors its backward needs; nothing is allocated or synchronised inside the kernels, so a whole step can
     be captured into a hipGraph.
 """
+import os
+
 import torch
 
 from . import ops
@@ -155,6 +157,18 @@ class LayerSpec:
         self.B, self.S, self.nheads, self.eps, self.pre_ln, self.mask_mode = B, S, nheads, eps, pre_ln, mask_mode
 
 
+GROUPED_WGRAD = [os.environ.get("TAV_GROUPED_WGRAD", "1") == "1"]
+
+
+def _layer_wgrads(pairs):
+    """Weight and bias gradients of one layer's linears, [(dY_lp, X_lp), ...] -> [(dW, db), ...].  One grouped launch in which
+    every tile sums over all tokens (no split slabs, no reduce kernels) when the layer's tiles fill the chip; else one TN GEMM each."""
+    tiles = sum(((a.shape[1] + 127) // 128) * ((b.shape[1] + 127) // 128) for a, b in pairs)
+    if GROUPED_WGRAD[0] and len(pairs) <= 4 and tiles >= 256:
+        return ops.gemm_tn_grouped(pairs, want_bias=True)
+    return [ops.gemm_tn(a, b, want_bias=True) for a, b in pairs]
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """One transformer layer.  params = (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2).
 
@@ -221,9 +235,7 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
         # FFN
-        dW2, dB2 = ops.gemm_tn(dy2_lp, h, want_bias=True)
         du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
-        dW1, dB1 = ops.gemm_tn(du, c, want_bias=True)
         if spec.pre_ln:
             dc = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
@@ -232,16 +244,16 @@ class EncoderLayerFn(torch.autograd.Function):
             g1 = ops.gemm_nt(du, w1_t, resid=dy2, out_dtype=torch.float32)
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
         # attention
-        dWo, dBo = ops.gemm_tn(dy1_lp, o, want_bias=True)
         do = ops.gemm_nt(dy1_lp, wo_t)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        dWqkv, dBqkv = ops.gemm_tn(dqkv, a, want_bias=True)
         if spec.pre_ln:
             da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
             g0, _, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=False)
         else:
             g0 = ops.gemm_nt(dqkv, wqkv_t, resid=dy1, out_dtype=torch.float32)
+        # the four weight (+bias) gradients of the layer: leaves nobody reads before the optimizer, issued last as ONE grouped launch
+        (dW2, dB2), (dW1, dB1), (dWo, dBo), (dWqkv, dBqkv) = _layer_wgrads([(dy2_lp, h), (du, c), (dy1_lp, o), (dqkv, a)])
         grads = [dg1, db1, dWqkv[:H], dBqkv[:H], dWqkv[H:2 * H], dBqkv[H:2 * H], dWqkv[2 * H:], dBqkv[2 * H:], dWo, dBo, dg2, db2, dW1, dB1, dW2, dB2]
         grads = [g if has else None for g, has in zip(grads, ctx.has)]
         return (g0, None, None, None, None, *grads)

@@ -116,6 +116,26 @@ def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb
     return (out, dbias) if want_bias else out
 
 
+def gemm_tn_grouped(pairs, want_bias=True):
+    """[(A_k [rows, N1_k], B_k [rows, N2_k]), ...] (<= 4, same rows and dtype) -> [(dW_k [N1_k, N2_k] f32, db_k [N1_k] f32 | None), ...]
+    in ONE launch, every tile summing over all rows (the weight gradients of one transformer layer)."""
+    n = len(pairs)
+    rows, dtype = pairs[0][0].shape[0], pairs[0][0].dtype
+    probs = (L.GemmTNProblem * n)()
+    outs = []
+    for k, (a, b) in enumerate(pairs):
+        assert a.shape[0] == rows and b.shape[0] == rows and a.dtype == dtype and b.dtype == dtype
+        N1, N2 = a.shape[1], b.shape[1]
+        dW = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+        db = torch.empty(N1, dtype=torch.float32, device=a.device) if want_bias else None
+        pr = probs[k]
+        pr.A, pr.B, pr.out, pr.dbias = ptr(a), ptr(b), ptr(dW), ptr(db)
+        pr.N1, pr.N2, pr.lda, pr.ldb = N1, N2, a.stride(0), b.stride(0)
+        outs.append((dW, db))
+    check(lib().tav_gemm_tn_grouped(probs, n, rows, dt(pairs[0][0]), stream()), "gemm_tn_grouped")
+    return outs
+
+
 def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):
     if M is None:
         M, N, ld = x.shape[-2], x.shape[-1], x.stride(-2)

@@ -75,6 +75,24 @@ def check_gemm_tn(dtype, M=1000, N1=256, N2=384, nbatch=1):
             _res("gemm_tn.dbias", dbias, a.float().sum(0), 1e-5)]
 
 
+def check_gemm_tn_grouped(dtype, M=777):
+    """Four weight gradients over the same (ragged) token axis in one launch; operands are column slices of wider buffers."""
+    shapes = [(384, 128), (128, 136), (256, 128), (128, 264)]
+    wide_a = _rnd(M, 640, dtype=dtype, seed=21)
+    pairs, refs = [], []
+    for k, (n1, n2) in enumerate(shapes):
+        a = wide_a[:, 64:64 + n1] if k == 0 else _rnd(M, n1, dtype=dtype, seed=22 + k)
+        b = _rnd(M, n2, dtype=dtype, seed=30 + k)
+        pairs.append((a, b))
+        refs.append((a.float().t() @ b.float(), a.float().sum(0)))
+    outs = ops.gemm_tn_grouped(pairs, want_bias=True)
+    rs = []
+    for k, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
+        rs.append(_res(f"gemm_tn_grouped[{dtype},M{M}].dW{k}", dW, rW, 2e-3 if dtype == torch.bfloat16 else 2e-5))
+        rs.append(_res(f"gemm_tn_grouped[{dtype},M{M}].db{k}", db, rb, 1e-5))
+    return rs
+
+
 def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
     """Conv1d(C,C,k,stride s) on channels-last activations as an NT GEMM over overlapping rows + its gradients."""
     T_out = (T_in - k) // s + 1
@@ -356,6 +374,8 @@ def all_checks():
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_tn(d))
         out.append(lambda d=dtype: check_gemm_tn(d, M=249, N1=768, N2=512, nbatch=3))
+        out.append(lambda d=dtype: check_gemm_tn_grouped(d))
+        out.append(lambda d=dtype: check_gemm_tn_grouped(d, M=64))
         out.append(lambda d=dtype: check_conv_as_gemm(d))
         out.append(lambda d=dtype: check_conv_as_gemm(d, k=2, T_in=100))
         for mode in (0, 1, 2):
