@@ -296,6 +296,15 @@ int tav_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* no
 int tav_adamw_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
                     int32_t ntensors, const float* clip_coef /*opt*/, const float* lr, float beta1, float beta2, float eps, float weight_decay,
                     int32_t* step, float* bias_corr, void* stream);
+/* Chunked forms of the two calls above for long parameter lists with very uneven sizes: chunk_prefix[t] (device, int32, ntensors entries)
+ * = index of tensor t's first chunk of tav_optim_chunk_elems() elements, nchunks = total; block c works on chunk c only.
+ * partials = workspace nchunks f32.  Same arithmetic as tav_sumsq_multi / tav_adamw_multi. */
+int tav_optim_chunk_elems(void);
+int tav_sumsq_chunked(const float* const* ptrs, const int64_t* sizes, const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks,
+                      float* partials, float* out_sumsq, void* stream);
+int tav_adamw_chunked(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                      const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks, const float* clip_coef, const float* lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t* step, float* bias_corr, void* stream);
 
 #ifdef __cplusplus
 }

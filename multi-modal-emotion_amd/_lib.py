@@ -114,6 +114,9 @@ _SIGS = {
     "tav_sumsq_multi": (C.c_int, [vp, vp, i32, vp, vp, vp]),
     "tav_clip_coef": (C.c_int, [vp, f32, vp, vp, vp]),
     "tav_adamw_multi": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
+    "tav_optim_chunk_elems": (C.c_int, []),
+    "tav_sumsq_chunked": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
+    "tav_adamw_chunked": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
 }
 
 _lib = None

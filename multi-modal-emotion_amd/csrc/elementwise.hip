@@ -402,6 +402,76 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* const* __restri
     }
 }
 
+// ---- chunked forms: block c handles chunk c of the concatenation of all tensors (chunk_prefix[t] = first chunk of tensor t, built once
+// on the host since the sizes are static).  Every block has OPT_CHUNK elements of work (except a tensor's last chunk): no empty blocks
+// for the ~400 small tensors, enough parallelism for the large ones, float4 accesses.
+constexpr int OPT_CHUNK = 16384;
+TAV_DEV int chunk_owner(const int32_t* __restrict__ prefix, int ntensors, int c) {
+    int lo = 0, hi = ntensors - 1;
+    while (lo < hi) {                               // last t with prefix[t] <= c
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void sumsq_chunk_kernel(const float* const* __restrict__ ptrs, const int64_t* __restrict__ sizes,
+                                                          const int32_t* __restrict__ prefix, int ntensors, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = chunk_owner(prefix, ntensors, c);
+    const long off = (long)(c - prefix[t]) * OPT_CHUNK;
+    const float* p = ptrs[t] + off;
+    long n = sizes[t] - off; n = n < OPT_CHUNK ? n : OPT_CHUNK;
+    float a = 0.f;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const long n4 = n >> 2;
+        for (long i = threadIdx.x; i < n4; i += 256) { const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i); a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += 256) a += p[i] * p[i];
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) a += p[i] * p[i];
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[c] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void adamw_chunk_kernel(float* const* __restrict__ params, const float* const* __restrict__ grads,
+                                                          float* const* __restrict__ m1, float* const* __restrict__ m2, const int64_t* __restrict__ sizes,
+                                                          const int32_t* __restrict__ prefix, int ntensors, const float* __restrict__ clip_coef,
+                                                          const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd, const float* __restrict__ bc) {
+    const float lr = lr_dev[0], bc1 = bc[0], bc2 = bc[1];
+    const int c = blockIdx.x, t = chunk_owner(prefix, ntensors, c);
+    const long off = (long)(c - prefix[t]) * OPT_CHUNK;
+    float* p = params[t] + off; const float* g = grads[t] + off; float* ea = m1[t] + off; float* es = m2[t] + off;
+    long n = sizes[t] - off; n = n < OPT_CHUNK ? n : OPT_CHUNK;
+    const float cc = clip_coef ? clip_coef[0] : 1.f;
+    const float decay = 1.f - lr * wd, step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    auto upd = [&](float& w, float gr, float& a, float& s2) {
+        gr *= cc;
+        w *= decay;
+        a = a * b1 + (1.f - b1) * gr;
+        s2 = s2 * b2 + (1.f - b2) * gr * gr;
+        w -= step * a / (sqrtf(s2) * rs2 + eps);
+    };
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ea) | reinterpret_cast<uintptr_t>(es)) & 15) == 0;
+    long done = 0;
+    if (al) {
+        const long n4 = n >> 2;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            f32x4 w = *reinterpret_cast<f32x4*>(p + 4 * i), a = *reinterpret_cast<f32x4*>(ea + 4 * i), s2 = *reinterpret_cast<f32x4*>(es + 4 * i);
+            const f32x4 gr = *reinterpret_cast<const f32x4*>(g + 4 * i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float wk = w[k], ak = a[k], sk = s2[k];
+                upd(wk, gr[k], ak, sk);
+                w[k] = wk; a[k] = ak; s2[k] = sk;
+            }
+            *reinterpret_cast<f32x4*>(p + 4 * i) = w; *reinterpret_cast<f32x4*>(ea + 4 * i) = a; *reinterpret_cast<f32x4*>(es + 4 * i) = s2;
+        }
+        done = 4 * n4;
+    }
+    for (long i = done + threadIdx.x; i < n; i += 256) upd(p[i], g[i], ea[i], es[i]);
+}
+
 }  // namespace tav
 using namespace tav;
 
@@ -604,6 +674,25 @@ extern "C" int tav_sumsq_multi(const float* const* ptrs, const int64_t* sizes, i
     if (ntensors <= 0 || ntensors > 65535) return TAV_ERR_SHAPE;
     hipLaunchKernelGGL(sumsq_multi_kernel, dim3(SUMSQ_BLOCKS, ntensors), dim3(256), 0, ST, ptrs, sizes, partials);
     hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, ST, partials, (long)ntensors * SUMSQ_BLOCKS, out_sumsq);
+    return tav_last_error();
+}
+extern "C" int tav_optim_chunk_elems(void) { return OPT_CHUNK; }
+extern "C" int tav_sumsq_chunked(const float* const* ptrs, const int64_t* sizes, const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks,
+                                 float* partials, float* out_sumsq, void* stream) {
+    if (!ptrs || !sizes || !chunk_prefix || !partials || !out_sumsq) return TAV_ERR_NULL;
+    if (ntensors <= 0 || nchunks <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(nchunks), dim3(256), 0, ST, ptrs, sizes, chunk_prefix, ntensors, partials);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, ST, partials, (long)nchunks, out_sumsq);
+    return tav_last_error();
+}
+extern "C" int tav_adamw_chunked(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                                 const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks, const float* clip_coef, const float* lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int32_t* step, float* bias_corr, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !chunk_prefix || !lr || !step || !bias_corr) return TAV_ERR_NULL;
+    if (ntensors <= 0 || nchunks <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ST, step, beta1, beta2, bias_corr);
+    hipLaunchKernelGGL(adamw_chunk_kernel, dim3(nchunks), dim3(256), 0, ST, params, grads, exp_avg, exp_avg_sq, sizes, chunk_prefix, ntensors, clip_coef, lr,
+                       beta1, beta2, eps, weight_decay, (const float*)bias_corr);
     return tav_last_error();
 }
 extern "C" int tav_clip_coef(const float* sumsq, float max_norm, float* coef_out, float* norm_out, void* stream) {

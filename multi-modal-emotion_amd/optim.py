@@ -32,6 +32,7 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = {}
         self._tables = None
+        self._chunks = None
         self.last_norm = None
         self._lr_dev = None          # device copies of lr / step counter: graph replay must not bake them into kernel args
         self._lr_host = None
@@ -72,10 +73,17 @@ class FusedAdamW:
         d_m = tm.set([self.state[p][0].data_ptr() for p in act])
         d_v = tv.set([self.state[p][1].data_ptr() for p in act])
         d_s = ts.set([p.numel() for p in act])
+        sizes = tuple(p.numel() for p in act)
+        if self._chunks is None or self._chunks[0] != sizes:        # chunk table of the chunked kernels: static as long as the sizes are
+            ce = lib().tav_optim_chunk_elems()
+            counts = torch.tensor([(s + ce - 1) // ce for s in sizes], dtype=torch.int64)
+            prefix = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+            self._chunks = (sizes, prefix.to(act[0].device), int(counts.sum()))
+        d_c, nchunks = self._chunks[1], self._chunks[2]
         coef = None
         if max_norm is not None:
-            part = torch.empty(lib().tav_sumsq_partials(n), dtype=torch.float32, device=act[0].device)
-            check(lib().tav_sumsq_multi(ptr(d_g), ptr(d_s), n, ptr(part), ptr(self._scal[0:1]), stream()), "sumsq_multi")
+            part = torch.empty(nchunks, dtype=torch.float32, device=act[0].device)
+            check(lib().tav_sumsq_chunked(ptr(d_g), ptr(d_s), ptr(d_c), n, nchunks, ptr(part), ptr(self._scal[0:1]), stream()), "sumsq_chunked")
             check(lib().tav_clip_coef(ptr(self._scal[0:1]), float(max_norm), ptr(self._scal[1:2]), ptr(self._scal[2:3]), stream()), "clip_coef")
             coef = self._scal[1:2]
             self.last_norm = self._scal[2:3]
@@ -83,8 +91,9 @@ class FusedAdamW:
             self._lr_pin[0] = self.lr
             self._scal[4:5].copy_(self._lr_pin, non_blocking=True)
             self._lr_host = self.lr
-        check(lib().tav_adamw_multi(ptr(d_p), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_s), n, ptr(coef), ptr(self._scal[4:5]), self.betas[0], self.betas[1],
-                                    self.eps, self.weight_decay, ptr(self._step_dev), ptr(self._scal[5:7]), stream()), "adamw_multi")
+        check(lib().tav_adamw_chunked(ptr(d_p), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_s), ptr(d_c), n, nchunks, ptr(coef), ptr(self._scal[4:5]),
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, ptr(self._step_dev), ptr(self._scal[5:7]), stream()),
+              "adamw_chunked")
         engine.bump_weight_epoch()          # parameters changed through raw pointers: refresh cached operand copies
         return self.last_norm
 
