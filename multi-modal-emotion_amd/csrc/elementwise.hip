@@ -225,14 +225,20 @@ __global__ __launch_bounds__(256) void mask_to_index_kernel(const uint8_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------ pooling / head / loss
+// block = 16 float4 columns x 16 row groups: every thread sums rows rg, rg+16, ... of its 4 columns (16-B loads, S/16 iterations)
 __global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int S, int W) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    float a = 0.f;
-    if (c < W) for (int s = rg; s < S; s += 4) a += x[((long)b * S + s) * W + c];
-    red[rg][threadIdx.x & 63] = a;
+    __shared__ f32x4 red[16][16];
+    const int b = blockIdx.y, cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + cq) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < W) for (int s = rg; s < S; s += 16) a += ld4(x + ((long)b * S + s) * W + c);
+    red[rg][cq] = a;
     __syncthreads();
-    if (rg == 0 && c < W) y[(long)b * W + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)S;
+    if (rg == 0 && c < W) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) a += red[k][cq];
+        st4(y + (long)b * W + c, a * (1.f / (float)S));
+    }
 }
 template <typename TL>
 __global__ void mean_pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, TL* __restrict__ dx_lp, long n4, int S, int W4) {
@@ -456,7 +462,29 @@ __global__ __launch_bounds__(256) void adamw_chunk_kernel(float* const* __restri
     long done = 0;
     if (al) {
         const long n4 = n >> 2;
-        for (long i = threadIdx.x; i < n4; i += 256) {
+        constexpr int U = 4;                        // 16 independent 16-B loads in flight per thread before the first use
+        long i = threadIdx.x;
+        for (; i + (U - 1) * 256 < n4; i += U * 256) {
+            f32x4 w[U], a[U], s2[U], gr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long j = 4 * (i + u * 256);
+                w[u] = *reinterpret_cast<f32x4*>(p + j); gr[u] = *reinterpret_cast<const f32x4*>(g + j);
+                a[u] = *reinterpret_cast<f32x4*>(ea + j); s2[u] = *reinterpret_cast<f32x4*>(es + j);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float wk = w[u][k], ak = a[u][k], sk = s2[u][k];
+                    upd(wk, gr[u][k], ak, sk);
+                    w[u][k] = wk; a[u][k] = ak; s2[u][k] = sk;
+                }
+                const long j = 4 * (i + u * 256);
+                *reinterpret_cast<f32x4*>(p + j) = w[u]; *reinterpret_cast<f32x4*>(ea + j) = a[u]; *reinterpret_cast<f32x4*>(es + j) = s2[u];
+            }
+        }
+        for (; i < n4; i += 256) {
             f32x4 w = *reinterpret_cast<f32x4*>(p + 4 * i), a = *reinterpret_cast<f32x4*>(ea + 4 * i), s2 = *reinterpret_cast<f32x4*>(es + 4 * i);
             const f32x4 gr = *reinterpret_cast<const f32x4*>(g + 4 * i);
 #pragma unroll
@@ -613,6 +641,7 @@ extern "C" int tav_mask_to_index(const uint8_t* mask, int32_t keep_value, int32_
 extern "C" int tav_mean_pool_fwd(const float* x, float* y, int64_t B, int64_t S, int64_t W, void* stream) {
     if (!x || !y) return TAV_ERR_NULL;
     if (B <= 0 || S <= 0 || W <= 0) return TAV_ERR_SHAPE;
+    if (W % 4) return TAV_ERR_SHAPE;
     hipLaunchKernelGGL(mean_pool_fwd_kernel, dim3(tav_cdiv(W, 64), (unsigned)B), dim3(256), 0, ST, x, y, (int)S, (int)W);
     return tav_last_error();
 }
