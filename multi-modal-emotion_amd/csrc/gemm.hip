@@ -548,20 +548,32 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     p.tiles_n = (p.N + 127) / 128;
     // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
     int tm = a->tile_m_hint & 15;                            // 2/3/4: 64/96/128-row tiles (4 waves); 8: 256-row tile (8 waves)
+    int nst = (a->tile_m_hint >> 4) & 15;                    // tuning: LDS ring depth 2..4 (0 = let the library choose)
     if (a->in_dtype != TAV_BF16 && tm == 8) tm = 4;
     if (tm != 8 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.tiles_n, nzb * p.nzg, a->in_dtype == TAV_BF16);
     const int bm = tm == 8 ? 256 : 32 * tm;
     p.tiles_m = (p.M + bm - 1) / bm;
+    const long wgs = (long)p.tiles_m * p.tiles_n * nzb * p.nzg;
+    // Ring depth.  Large grids run two workgroups per CU and are bound by the L2->LDS intake, where depth changes nothing: 2.
+    // A grid of at most one workgroup per CU (the text / audio / fusion branches' N = 768 GEMMs) is LATENCY bound instead -- a lone
+    // workgroup waits out every DMA round trip -- and has the whole LDS to itself: 4 buffers (3 tiles in flight).
+    if (tm == 8) nst = 3;
+    else if (nst < 2 || nst > 4) nst = (wgs <= 256 && a->in_dtype == TAV_BF16) ? 4 : 2;
+    if (a->in_dtype != TAV_BF16) nst = 2;
     dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm == 8 ? 512 : 256);
-    // 4 waves: 2-deep ring, two workgroups per CU.  8 waves: 3-deep ring = 144 KB (one workgroup per CU; the f32 epilogue tile of
-    // 256 x 128 needs 128 KB of it)
-    const size_t lds = tm == 8 ? (size_t)3 * (256 + 128) * 128 : (size_t)2 * (bm + 128) * 128;
-#define TAV_NT_LAUNCH(TT, TOO)                                                                                 \
-    do {                                                                                                       \
-        if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8>), grid, block, lds, stream, p);       \
-        else if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 2, 4>), grid, block, lds, stream, p);  \
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, 2, 4>), grid, block, lds, stream, p);  \
-        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, 2, 4>), grid, block, lds, stream, p);               \
+    const size_t lds = (size_t)nst * (bm + 128) * 128;       // 8 waves: 3 x 48 KB (the f32 epilogue tile of 256 x 128 needs 128 KB of it)
+#define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                              \
+    do {                                                                                                          \
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4>), grid, block, lds, stream, p);         \
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, NS, 4>), grid, block, lds, stream, p);    \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, NS, 4>), grid, block, lds, stream, p);                 \
+    } while (0)
+#define TAV_NT_LAUNCH(TT, TOO)                                                                                    \
+    do {                                                                                                          \
+        if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8>), grid, block, lds, stream, p);          \
+        else if (nst == 4) TAV_NT_LAUNCH_S(TT, TOO, 4);                                                            \
+        else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                            \
+        else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                          \
     } while (0)
     if (a->in_dtype == TAV_BF16) {
         if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
@@ -572,6 +584,7 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4>), grid, block, lds, stream, p);
     }
 #undef TAV_NT_LAUNCH
+#undef TAV_NT_LAUNCH_S
     return (int)hipGetLastError();
 }
 

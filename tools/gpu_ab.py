@@ -75,3 +75,17 @@ if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/12
             lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm), iters=30, reps=5)
             row.append(f"tm{tm} {lo:6.1f}")
         print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: " + "  ".join(row) + "  us")
+if "ring" in what:        # small-grid NT GEMMs (text / audio / fusion shapes): LDS ring depth sweep (hint = tm + 16 * depth)
+    for (name, M, N, K) in [("text out", B * 128, 768, 768), ("text ffn2", B * 128, 768, 3072), ("text qkv", B * 128, 2304, 768), ("text ffn1", B * 128, 3072, 768),
+                            ("audio out", B * 249, 768, 768), ("audio ffn2", B * 249, 768, 3072), ("audio ffn1", B * 249, 3072, 768),
+                            ("fusion out", B * 481, 768, 768), ("fusion ffn2", B * 481, 768, 3072), ("fusion qkv", B * 481, 2304, 768)]:
+        a, b = rnd(M, K), rnd(N, K)
+        bias = torch.randn(N, device=dev)
+        row = []
+        lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, out_dtype=torch.float32 if N == 768 else None), iters=30, reps=5)
+        row.append(f"auto {lo:5.1f}")
+        for tm in (2, 3, 4):
+            for nst in (2, 3, 4):
+                lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm + 16 * nst, out_dtype=torch.float32 if N == 768 else None), iters=30, reps=5)
+                row.append(f"tm{tm}s{nst} {lo:5.1f}")
+        print(f"[{tag}] gemm_nt {name:11s} M={M:5d} N={N:4d} K={K:4d}: " + " ".join(row))
