@@ -8,7 +8,7 @@
 namespace tav {
 
 constexpr int C0_TT = 32;      // output steps per workgroup (conv0 forward)
-constexpr int C0_BT = 64;      // output steps per workgroup (conv0 weight gradient): short chunks => ~2000 workgroups, the loop is latency bound
+constexpr int C0_BT = 256;     // output steps per workgroup of the conv0 weight gradient (4 time groups x 64 steps)
 constexpr int C0_MAXK = 16;
 
 // y[b][t][c] = sum_j x[b][s*t + j] * w[c][j] + bias[c];  thread owns channels {tid, tid+256, ...}
@@ -39,11 +39,15 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
     }
 }
 
-// partial[block][c][K+1]: dw[c][j] = sum_t dy[t][c] x[s*t+j], last column = bias gradient
+// partial[block][c][K+1]: dw[c][j] = sum_t dy[t][c] x[s*t+j], last column = bias gradient.
+// Workgroup = one chunk of C0_BT output steps x 512 channels: thread (cq, tg) owns channels 8cq..8cq+7 and the steps tg, tg+4, ... of
+// the chunk, reading 8 channels per load (16 B of bf16): 64 x 16-B loads per thread instead of 256 x 2-B ones (the old form was latency
+// bound at 0.5 TB/s).  The four time groups are summed through LDS.
 template <typename TD>
 __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const float* __restrict__ wave, const TD* __restrict__ dy, float* __restrict__ partial,
                                                           int T_in, int T_out, int C, int K, int stride, int nchunks) {
     __shared__ float xs[C0_BT * 8 + C0_MAXK];
+    __shared__ float red[2][64][89];                        // [slot][cq][8 channels x 11 accumulators] (+1: bank spread)
     const int b = blockIdx.y, t0 = blockIdx.x * C0_BT;
     const int nx = C0_BT * stride + K;
     for (int i = threadIdx.x; i < nx; i += 256) {
@@ -52,22 +56,64 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(const float* __restric
     }
     __syncthreads();
     const long blk = (long)b * nchunks + blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc[C0_MAXK + 1];
+    const int cq = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int tmax = (T_out - t0) < C0_BT ? (T_out - t0) : C0_BT;
+    constexpr int KA = 11;                                   // accumulators per channel: K taps (<= 10 here) + bias
+    for (int c0 = cq * 8; c0 < C; c0 += 512) {
+        float acc[8][KA];
 #pragma unroll
-        for (int j = 0; j <= C0_MAXK; ++j) acc[j] = 0.f;
-        const int tmax = (T_out - t0) < C0_BT ? (T_out - t0) : C0_BT;
-#pragma unroll 8
-        for (int tt = 0; tt < tmax; ++tt) {
-            const int t = t0 + tt;
-            const float d = ET<TD>::ld(dy + ((long)b * T_out + t) * C + c);
+        for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int j = 0; j < C0_MAXK; ++j) if (j < K) acc[j] += d * xs[tt * stride + j];
-            acc[C0_MAXK] += d;
+            for (int j = 0; j < KA; ++j) acc[e][j] = 0.f;
+#pragma unroll 2
+        for (int tt = tg; tt < tmax; tt += 4) {
+            const TD* src = dy + ((long)b * T_out + t0 + tt) * C + c0;
+            const f32x4 d0 = ld4(src), d1 = ld4(src + 4);
+            const float d[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+            for (int j = 0; j < KA - 1; ++j) {
+                const float xv = j < K ? xs[tt * stride + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e][j] += d[e] * xv;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e][KA - 1] += d[e];
         }
-        float* o = partial + (blk * C + c) * (K + 1);
-        for (int j = 0; j < K; ++j) o[j] = acc[j];
-        o[K] = acc[C0_MAXK];
+        // tree over the four time groups (= waves): 2,3 -> 0,1, then 1 -> 0
+        if (tg >= 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < KA; ++j) red[tg - 2][cq][e * KA + j] = acc[e][j];
+        }
+        __syncthreads();
+        if (tg < 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < KA; ++j) acc[e][j] += red[tg][cq][e * KA + j];
+        }
+        __syncthreads();
+        if (tg == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < KA; ++j) red[0][cq][e * KA + j] = acc[e][j];
+        }
+        __syncthreads();
+        if (tg == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float* o = partial + (blk * C + c0 + e) * (K + 1);
+#pragma unroll
+                for (int j = 0; j < KA; ++j) {
+                    const float v = acc[e][j] + red[0][cq][e * KA + j];
+                    if (j < K) o[j] = v;
+                    else if (j == KA - 1) o[K] = v;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 // 64 outputs x 4 partial groups per workgroup (the partial index is the slow axis: coalesced over outputs)
@@ -207,7 +253,7 @@ extern "C" int tav_conv0_bwd_partials(int64_t B, int64_t T_out, int64_t C, int64
 extern "C" int tav_conv0_bwd_w(const float* wave, const void* dy, int32_t dt, float* dw, float* dbias, float* partials, int64_t B, int64_t T_in, int64_t T_out,
                                int64_t C, int64_t K, int64_t stride, int32_t accumulate, void* stream) {
     if (!wave || !dy || !dw || !partials) return TAV_ERR_NULL;
-    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || K <= 0 || K > C0_MAXK || stride <= 0 || stride > 8) return TAV_ERR_SHAPE;
+    if (B <= 0 || T_in <= 0 || T_out <= 0 || C <= 0 || C % 8 || K <= 0 || K > 10 || stride <= 0 || stride > 8) return TAV_ERR_SHAPE;
     const int nchunks = (int)((T_out + C0_BT - 1) / C0_BT);
     dim3 grid(nchunks, (unsigned)B);
     if (dt == TAV_BF16) hipLaunchKernelGGL((conv0_bwd_w_kernel<bf16>), grid, dim3(256), 0, ST, wave, (const bf16*)dy, partials, (int)T_in, (int)T_out, (int)C, (int)K, (int)stride, nchunks);
