@@ -139,7 +139,7 @@ def gemm_tn_grouped(pairs, want_bias=True):
 def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):
     if M is None:
         M, N, ld = x.shape[-2], x.shape[-1], x.stride(-2)
-    nparts = max(1, min(256, (M + 255) // 256))
+    nparts = max(1, min(256, (M + 15) // 16))        # a workgroup column-sums >= 16 rows (hundreds of rows per workgroup at small M was latency bound)
     part = workspace("colsum", nparts * N, x.device)
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)

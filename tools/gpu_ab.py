@@ -89,3 +89,11 @@ if "ring" in what:        # small-grid NT GEMMs (text / audio / fusion shapes): 
                 lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm + 16 * nst, out_dtype=torch.float32 if N == 768 else None), iters=30, reps=5)
                 row.append(f"tm{tm}s{nst} {lo:5.1f}")
         print(f"[{tag}] gemm_nt {name:11s} M={M:5d} N={N:4d} K={K:4d}: " + " ".join(row))
+if "ln" in what:          # LayerNorm backward (with dgamma/dbeta) at the four branch sizes
+    for (name, rows) in [("video", B * 1464), ("fusion", B * 481), ("audio", B * 249), ("text", B * 128)]:
+        x = torch.randn(rows, 768, device=dev)
+        g, bt = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+        _, _, mean, rstd = ops.ln_fwd(x, g, bt, 1e-12, want_f32=False, lp_dtype=torch.bfloat16)
+        dy = torch.randn(rows, 768, device=dev)
+        lo, med = timeit(lambda: ops.ln_bwd(dy, x, g, bt, mean, rstd, want_f32=True, lp_dtype=torch.bfloat16))
+        print(f"[{tag}] ln_bwd {name:7s} rows={rows:6d}: min {lo:6.1f} us  med {med:6.1f} us")
