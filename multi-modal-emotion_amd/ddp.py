@@ -13,10 +13,11 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    def __init__(self, params, bucket_mb=48.0, process_group=None, reduce_dtype=None):
+    def __init__(self, params, bucket_mb=48.0, process_group=None, reduce_dtype=None, single_rank_ok=False):
         self.params = [p for p in params if p.requires_grad]
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._active = self.world > 1 or (single_rank_ok and dist.is_initialized())     # single_rank_ok: run the collectives even alone (tests)
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
         self.reduce_dtype = reduce_dtype            # e.g. torch.bfloat16 halves the bytes on the wire
         self.order = None                            # ready order learned during the first backward
@@ -50,7 +51,7 @@ class BucketedAllReduce:
 
     # ---- hooks -----------------------------------------------------------------------------------------------------
     def _on_ready(self, p):
-        if self.world == 1:
+        if not self._active:
             return
         if self.buckets is None:
             self._ready.append(p)          # first step: learn the order, reduce everything in finish()
@@ -92,7 +93,7 @@ class BucketedAllReduce:
 
     def finish(self):
         """Join all outstanding reductions; afterwards every p.grad holds the mean over ranks."""
-        if self.world == 1:
+        if not self._active:
             return
         if self.buckets is None:                     # first step: plan from the observed order, then reduce all
             seen = set()

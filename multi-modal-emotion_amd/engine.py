@@ -11,6 +11,7 @@ Design (MI355X-first):
     be captured into a hipGraph.
 """
 import os
+import weakref
 
 import torch
 
@@ -41,14 +42,25 @@ class WeightCache:
         self.pol = policy
         self.d = {}
 
+    @staticmethod
+    def _same(refs, params):
+        """Entries are keyed by id(parameter); a dead parameter's id can be handed to a new one, so every entry also holds weak
+        references and is only valid while they still resolve to the very same objects."""
+        live = [p for p in params if p is not None]
+        return len(refs) == len(live) and all(r() is p for r, p in zip(refs, live))
+
+    @staticmethod
+    def _refs(params):
+        return tuple(weakref.ref(p) for p in params if p is not None)
+
     def _get(self, key, params, build):
         ver = (_EPOCH[0],) + tuple(p._version for p in params if p is not None)
         e = self.d.get(key)
-        if e is not None and e[0] == ver:
+        if e is not None and e[0] == ver and self._same(e[2], params):
             return e[1]
         with torch.no_grad():
             val = build()
-        self.d[key] = (ver, val)
+        self.d[key] = (ver, val, self._refs(params))
         return val
 
     def linear(self, w):
@@ -82,6 +94,8 @@ class WeightCache:
         params = (wq, wk, wv, bq, bk, bv, wo, w1, w2)
         ver = (_EPOCH[0],) + tuple(p._version for p in params if p is not None)
         e = self.d.get(key)
+        if e is not None and not self._same(e[3], params):
+            e = None                                              # another (dead) layer's entry under a recycled id: rebuild everything
         if e is not None and e[0] == ver:
             return e[1]
         with torch.no_grad():
@@ -107,7 +121,7 @@ class WeightCache:
             else:
                 val, aux = e[1], e[2]
             ops.cast_weights_multi(aux[0], aux[1], aux[2])       # one workgroup per 32x32 tile of the largest tensor
-        self.d[key] = (ver, val, aux)
+        self.d[key] = (ver, val, aux, self._refs(params))
         return val
 
     def conv(self, w):

@@ -7,6 +7,7 @@ evaluate_tav :166-167), running on libtavhip.  Differences, all forced by the MI
   * with torch.distributed initialised, gradients are averaged over ranks by ddp.BucketedAllReduce overlapped with backward.
 """
 import math
+import os
 
 import torch
 
@@ -66,8 +67,9 @@ class TrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad] + [p for p in PREFormer.parameters() if p.requires_grad]
         self.opt = FusedAdamW(self.params, lr=lr, weight_decay=weight_decay)
         self.reducer = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            self.reducer = tav_ddp.BucketedAllReduce(self.params, bucket_mb=bucket_mb, reduce_dtype=reduce_dtype)
+        alone_ok = os.environ.get("TAV_DDP_SINGLE_RANK", "0") == "1"         # exercise the RCCL path with one rank (tests)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and (torch.distributed.get_world_size() > 1 or alone_ok):
+            self.reducer = tav_ddp.BucketedAllReduce(self.params, bucket_mb=bucket_mb, reduce_dtype=reduce_dtype, single_rank_ok=alone_ok)
 
     def forward_backward(self, input, label, check="train", epoch=0, n_visual_true=None):
         loss = get_statistics(input, label, self.model, self.pre, self.criterion, None, check=check, epoch=epoch, n_visual_true=n_visual_true)
