@@ -110,6 +110,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libtavhip has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    alone_ddp = world == 1 and os.environ.get("TAV_DDP_SINGLE_RANK", "0") == "1"      # exercise the data-parallel step with one rank
+    if alone_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=dev)
     if args.gpus != world:
@@ -157,7 +162,43 @@ def main():
     # hipGraph: capture one whole step (fwd, loss, bwd, clip, AdamW, weight re-casts) and replay it -- ~3000 kernel launches per
     # step would otherwise cost the Python host about as long as the GPU needs to run them.
     graph, eager_step = None, one_step
-    if args.graph and world == 1:
+    if args.graph and stepper.reducer is not None and not args.no_optimizer:
+        # Data parallel: two graphs per step with the gradient all-reduce issued eagerly between them, so that no RCCL call is ever
+        # captured: G1 = forward + loss + backward + pack gradients into their buckets, then one all-reduce (mean) per bucket on the
+        # work stream, then G2 = clip_grad_norm_ + AdamW reading the reduced buckets.  The host only enqueues ~35 collectives per
+        # step (the eager hook-based path -- all-reduce overlapped with the backward on a side stream -- is host bound at ~44 ms/step).
+        try:
+            from tav_amd import engine
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            engine.bump_weight_epoch()
+            stepper.opt.zero_grad()
+            stepper.reducer.set_manual(True, bucket_mb=256.0)
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=work_stream):
+                static_loss = stepper.forward_backward(inp, labels, check="val", epoch=0, n_visual_true=n_true)
+                stepper.reducer.pack_all()
+            with torch.cuda.graph(g2, stream=work_stream, pool=g1.pool()):
+                stepper.update()
+            graph = (g1, g2)
+
+            def one_step():                                  # noqa: F811
+                g1.replay()
+                stepper.reducer.reduce_packed()
+                g2.replay()
+                return static_loss
+            for _ in range(2):
+                one_step()
+            torch.cuda.synchronize()
+            log(f"[rank {rank}] step captured into two hipGraphs around {len(stepper.reducer.buckets)} eager all-reduces")
+        except Exception as e:
+            import traceback
+            log(f"[rank {rank}] graph capture failed ({type(e).__name__}); falling back to eager\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
+            stepper.reducer.set_manual(False)
+            graph, one_step = None, eager_step
+            torch.cuda.synchronize()
+    elif args.graph and world == 1:
         try:
             from tav_amd import engine
             torch.cuda.synchronize()
@@ -233,7 +274,7 @@ def main():
                        "step": "PreFormer+TAVForMAE fwd, CE, bwd" + (", grad all-reduce (RCCL)" if world > 1 else "")
                                + ("" if args.no_optimizer else ", clip_grad_norm_, AdamW"),
                        "weights": "random init (seeded), no checkpoints offline", "final_loss": round(final_loss, 5),
-                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "launch": ("two hipGraphs + eager RCCL all-reduce" if isinstance(graph, tuple) else "hipGraph replay") if graph is not None else "eager",
                        "mfma_util_whole_step": round(step_flops / (elapsed / args.steps) / (MFMA_PEAK_BF16_TFLOPS * 1e12), 4)},
         }
         if roof is not None:
@@ -241,7 +282,7 @@ def main():
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or alone_ddp:
         torch.distributed.destroy_process_group()
 
 

@@ -25,6 +25,7 @@ class BucketedAllReduce:
         self._ready = []
         self._pending = {}
         self._works = []
+        self._manual = False
         self._cuda = self.params[0].is_cuda
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"    # RCCL has AVG; gloo sums then scales
         self.side = torch.cuda.Stream() if self._cuda else None
@@ -51,7 +52,7 @@ class BucketedAllReduce:
 
     # ---- hooks -----------------------------------------------------------------------------------------------------
     def _on_ready(self, p):
-        if not self._active:
+        if not self._active or self._manual:
             return
         if self.buckets is None:
             self._ready.append(p)          # first step: learn the order, reduce everything in finish()
@@ -93,7 +94,7 @@ class BucketedAllReduce:
 
     def finish(self):
         """Join all outstanding reductions; afterwards every p.grad holds the mean over ranks."""
-        if not self._active:
+        if not self._active or self._manual:
             return
         if self.buckets is None:                     # first step: plan from the observed order, then reduce all
             seen = set()
@@ -123,6 +124,48 @@ class BucketedAllReduce:
         self._pending = {}
         if self._cuda:
             torch.cuda.current_stream().wait_stream(self.side)
+
+    # ---- graph mode: no hooks, no side stream.  The backward (captured in one hipGraph) ends with pack_all(); the collectives are
+    # issued eagerly between that graph and the optimizer graph (no RCCL call is ever captured); see bench.py.
+    def set_manual(self, on=True, bucket_mb=None):
+        """Graph mode on/off.  Turning it on drops the learned bucket plan: pack_all() re-plans from the parameter list order, which
+        is identical on every rank by construction (and may use larger buckets: nothing overlaps in this mode)."""
+        self._manual = bool(on)
+        if on:
+            self.buckets = None
+            self._pending, self._works, self._ready = {}, [], []
+            if bucket_mb is not None:
+                self.bucket_bytes = int(bucket_mb * 2 ** 20)
+
+    def pack_all(self):
+        """Copy every gradient into its bucket and re-point .grad at the bucket view (call right after backward; capturable)."""
+        if self.buckets is None:
+            self._plan([p for p in reversed(self.params) if p.grad is not None])
+        with torch.no_grad():
+            for plist, flat in self.buckets:
+                live = [p for p in plist if p.grad is not None]
+                if len(live) != len(plist):
+                    raise RuntimeError("graph-mode reducer needs every bucketed parameter to receive a gradient each step")
+                views, off = [], 0
+                for p in plist:
+                    n = p.numel()
+                    views.append(flat[off:off + n].view_as(p))
+                    off += n
+                torch._foreach_copy_(views, [p.grad for p in plist])
+                for p, v in zip(plist, views):
+                    p.grad = v
+
+    def reduce_packed(self):
+        """All-reduce (mean) the packed buckets on the current stream (eager)."""
+        if not self._active:
+            return
+        for _, flat in self.buckets:
+            buf = flat if self.reduce_dtype is None else flat.to(self.reduce_dtype)
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg)
+            if buf is not flat:
+                flat.copy_(buf)
+            if not self._avg:
+                flat.mul_(1.0 / self.world)
 
     def remove(self):
         for h in self._hooks:

@@ -310,10 +310,15 @@ def test_rccl_reducer_single_rank(gpu, monkeypatch):
         model.cuda()
         monkeypatch.setenv("TAV_DDP_SINGLE_RANK", "1" if ddp else "0")
         stepper = TrainStep(model, pre, CrossEntropyLoss(), lr=1e-4, bucket_mb=1.0)
-        assert (stepper.reducer is not None) == ddp
+        assert (stepper.reducer is not None) == bool(ddp)
+        if ddp == "manual":                   # graph-mode reducer (bench.py with N > 1): pack after backward, collectives issued by the caller
+            stepper.reducer.set_manual(True, bucket_mb=4.0)
         out = []
         for _ in range(2):
             loss = stepper.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4)
+            if ddp == "manual":
+                stepper.reducer.pack_all()
+                stepper.reducer.reduce_packed()
             torch.cuda.synchronize()
             out.append((loss.item(), {k: p.grad.clone() for k, p in list(model.named_parameters()) + list(pre.named_parameters()) if p.grad is not None}))
             stepper.update()
@@ -327,11 +332,12 @@ def test_rccl_reducer_single_rank(gpu, monkeypatch):
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         created = True
     try:
-        plain, ddp = run(False), run(True)
+        plain, ddp, manual = run(False), run(True), run("manual")
     finally:
         if created:
             dist.destroy_process_group()
-    for step, ((l0, g0), (l1, g1)) in enumerate(zip(plain, ddp)):
+    for step, ((l0, g0), (l1, g1)) in enumerate(list(zip(plain, ddp)) + list(zip(plain, manual))):
+        step = step % 2
         assert g0.keys() == g1.keys()
         if step == 0:                         # identical weights: everything but the atomically accumulated embedding tables is bitwise equal
             assert l0 == l1
