@@ -161,6 +161,27 @@ def _to_lp(pol, x32):
     return x32 if pol.f32 else ops.cast2d(x32, pol.lp)
 
 
+# A pre-LN layer's backward starts by casting the incoming f32 gradient to the operand dtype.  When that gradient is the very tensor
+# the next layer's backward just produced (LN backward can emit the low-precision copy for free), the copy travels beside it:
+# one entry per stream, matched by tensor identity (a summed / re-materialised gradient never matches and is cast as before).
+_LP_HINT = {}
+
+
+_LP_HINT_ON = os.environ.get("TAV_LP_HINT", "1") == "1"
+
+
+def _hint_set(g32, glp):
+    if _LP_HINT_ON and glp is not None and g32 is not None and g32.is_cuda:
+        _LP_HINT[torch.cuda.current_stream().cuda_stream] = (g32, glp)
+
+
+def _hint_take(g):
+    if not g.is_cuda:
+        return None
+    e = _LP_HINT.pop(torch.cuda.current_stream().cuda_stream, None)
+    return e[1] if e is not None and e[0] is g else None
+
+
 def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
@@ -244,7 +265,8 @@ class EncoderLayerFn(torch.autograd.Function):
         _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
         g2 = _c(g2)
         if spec.pre_ln:
-            dy2, dy2_lp = g2, _to_lp(pol, g2)
+            hint = None if pol.f32 else _hint_take(g2)
+            dy2, dy2_lp = g2, (hint if hint is not None else _to_lp(pol, g2))
             dg2 = db2 = None
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
@@ -263,7 +285,9 @@ class EncoderLayerFn(torch.autograd.Function):
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
         if spec.pre_ln:
             da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
-            g0, _, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=False)
+            g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON and not pol.f32)
+            if not pol.f32:
+                _hint_set(g0, g0_lp)
         else:
             g0 = ops.gemm_nt(dqkv, wqkv_t, resid=dy1, out_dtype=torch.float32)
         # the four weight (+bias) gradients of the layer: leaves nobody reads before the optimizer, issued last as ONE grouped launch
