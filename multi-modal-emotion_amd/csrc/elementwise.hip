@@ -29,9 +29,35 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, TD* __restrict
 
 // Multi-tensor form: blockIdx.y selects a descriptor (one launch refreshes every operand copy of a transformer layer).
 struct CastDesc { const float* src; void* dst; void* dst_t; long ld_n, ld_t; int R, C, dtype, pad; };
+// bf16 matrices with R, C multiples of 64 and both copies wanted (every GEMM weight): 64x64 tiles, 16-B loads, 8-B stores (128-B row
+// segments) -- the 32x32 / 2-B-store form below ran at 2.1 TB/s
+__device__ void cast_weight_tile64(const CastDesc& d, float (*tile)[65], int t, int tiles_c) {
+    const int c0 = (t % tiles_c) * 64, r0 = (t / tiles_c) * 64;
+    const int q = threadIdx.x & 15, h = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = h + 16 * i;
+        const f32x4 v = ld4(d.src + (long)(r0 + row) * d.C + c0 + 4 * q);
+        st4((bf16*)d.dst + (long)(r0 + row) * d.ld_n + c0 + 4 * q, v);
+        tile[row][4 * q] = v[0]; tile[row][4 * q + 1] = v[1]; tile[row][4 * q + 2] = v[2]; tile[row][4 * q + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = h + 16 * i;
+        const f32x4 v = {tile[4 * q][c], tile[4 * q + 1][c], tile[4 * q + 2][c], tile[4 * q + 3][c]};
+        st4((bf16*)d.dst_t + (long)(c0 + c) * d.ld_t + r0 + 4 * q, v);
+    }
+    __syncthreads();
+}
 __global__ void cast_weight_multi_kernel(const CastDesc* __restrict__ descs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     const CastDesc d = descs[blockIdx.y];
+    if (d.dtype == TAV_BF16 && d.dst && d.dst_t && (d.R & 63) == 0 && (d.C & 63) == 0 && (d.ld_n & 3) == 0 && (d.ld_t & 3) == 0) {
+        const int tc = d.C >> 6, nt = tc * (d.R >> 6);
+        for (int t = blockIdx.x; t < nt; t += gridDim.x) cast_weight_tile64(d, tile, t, tc);      // block-uniform loop
+        return;
+    }
     const int tiles_c = (d.C + 31) >> 5, tiles_r = (d.R + 31) >> 5;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {      // block-uniform loop
