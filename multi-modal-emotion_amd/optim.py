@@ -50,7 +50,7 @@ class FusedAdamW:
         if self._tables is None or self._tables[0].host.numel() < n:
             self._tables = tuple(_PtrTable(max(n, len(self.params)), dev) for _ in range(5))
             self._scal = torch.zeros(8, dtype=torch.float32, device=dev)
-            self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._step_dev = torch.full((1,), int(getattr(self, "_loaded_step", 0)), dtype=torch.int32, device=dev)
             self._lr_pin = torch.empty(1, dtype=torch.float32).pin_memory()
         for p in act:
             if p not in self.state:
@@ -100,9 +100,46 @@ class FusedAdamW:
     def step(self):
         return self.clip_and_step(None)
 
+    # ---- checkpoint format of torch.optim.AdamW (reference utils/global_functions.py:199-258 saves optimizer.state_dict() into best.pt and
+    # reloads it into a fresh AdamW over the same parameter list): {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}
+    def state_dict(self):
+        step = self.step_count
+        state = {}
+        for i, p in enumerate(self.params):
+            if p in self.state:
+                m, v = self.state[p]
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        idx = [i for g in groups for i in g["params"]]
+        if len(idx) != len(self.params):
+            raise ValueError(f"optimizer state has {len(idx)} parameters, this optimizer {len(self.params)}")
+        g0 = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        self._lr_host = None
+        steps = set()
+        for pos, i in enumerate(idx):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            p = self.params[pos]
+            if st["exp_avg"].shape != p.shape:
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+            self.state[p] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(), st["exp_avg_sq"].to(p.device, torch.float32).contiguous().clone())
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused update keeps one counter (torch semantics when all parameters train together)")
+        self._loaded_step = steps.pop() if steps else 0
+        if self._tables is not None:
+            self._step_dev.fill_(self._loaded_step)
+
     @property
     def step_count(self):
-        return int(self._step_dev.item()) if self._tables is not None else 0
+        return int(self._step_dev.item()) if self._tables is not None else int(getattr(self, "_loaded_step", 0))
 
 
 def grad_norm(params):

@@ -13,6 +13,7 @@ import torch
 
 from .. import ddp as tav_ddp
 from ..optim import FusedAdamW
+from ..utils.global_functions import checkpoint_file, load_model, save_model
 
 try:                                    # optional, as in the reference's environment
     import wandb
@@ -30,10 +31,22 @@ class CosineWarmRestarts:
 
     def step(self, epoch):
         t_cur = epoch % self.T_0
+        self._t_cur, self._last_epoch = t_cur, epoch
         self.opt.lr = self.base_lr * (1 + math.cos(math.pi * t_cur / self.T_0)) / 2
 
     def get_last_lr(self):
         return [self.opt.lr]
+
+    def state_dict(self):
+        """Keys of torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.state_dict() that define the schedule."""
+        return {"T_0": self.T_0, "T_i": self.T_0, "T_mult": 1, "eta_min": 0, "T_cur": getattr(self, "_t_cur", 0), "base_lrs": [self.base_lr],
+                "last_epoch": getattr(self, "_last_epoch", 0), "_last_lr": [self.opt.lr]}
+
+    def load_state_dict(self, sd):
+        self.T_0, self.base_lr = sd["T_0"], sd["base_lrs"][0]
+        self._t_cur, self._last_epoch = sd.get("T_cur", 0), sd.get("last_epoch", 0)
+        if sd.get("_last_lr"):
+            self.opt.lr = sd["_last_lr"][0]
 
 
 def get_statistics(input, label, model, PREFormer, criterion, Metric, check="train", epoch=None, n_visual_true=None):
@@ -99,8 +112,22 @@ def validate(val_dataloader, model, PREFormer, criterion, Metric, name="val"):
     return total / len(val_dataloader)
 
 
-def not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val):
+def _save_if_better(val_loss, prev_val_loss, model, PREFormer, stepper, criterion, scheduler, epoch, batch_idx, path, log_val, patience):
+    """reference :72-82 / :108-118: keep the best validation loss, save best.pt on improvement, count patience otherwise."""
     global PATIENCE_ITER
+    if val_loss < prev_val_loss:
+        PATIENCE_ITER = 0
+        print(f"we have seen loss decrease the previous best and we are updating our best loss val to {val_loss}")
+        if path is not None:
+            save_model(model, PREFormer, stepper.opt, criterion, scheduler, epoch, batch_idx, path, log_val)
+        return val_loss, False
+    PATIENCE_ITER += 1
+    print(f"we have seen loss increase for {PATIENCE_ITER} steps and validation loss is {val_loss}, and previous best validtion loss is {prev_val_loss}")
+    return prev_val_loss, PATIENCE_ITER == patience
+
+
+def not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val, path=None):
+    """reference :52-83: one optimisation step per batch."""
     iters = len(train_dataloader)
     total_loss_train = 0.0
     for batch_idx, (train_input, train_label) in enumerate(train_dataloader):
@@ -114,33 +141,68 @@ def not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, cr
         if ((batch_idx + 1) % log_val == 0) or (batch_idx + 1 == iters):
             log(Metric, total_loss_train / iters, "train")
             val_loss = validate(val_dataloader, model, PREFormer, criterion, Metric, name="val")
-            if val_loss < prev_val_loss:
-                PATIENCE_ITER = 0
-                prev_val_loss = val_loss
-            else:
-                PATIENCE_ITER += 1
-                if PATIENCE_ITER == patience:
-                    break
+            prev_val_loss, stop = _save_if_better(val_loss, prev_val_loss, model, PREFormer, stepper, criterion, scheduler, epoch, batch_idx, path, log_val, patience)
+            if stop:
+                break
     return prev_val_loss
 
 
-def one_epoch(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, epoch_switch, patience, Metric, prev_val_loss):
-    # the reference alternates with a dialogue-level grad-accumulation variant (:85-119) on odd epochs; that variant steps
-    # every batch as well, so the per-step arithmetic (the hot path) is the same -- see SURVEY.md §8f-4.
-    return not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, 2400)
+def grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val, path=None):
+    """reference :87-119, the dialogue-level variant used on epochs with epoch % epoch_switch != 0.  Kept with its quirk: the loss is
+    divided by the dialogue length (`dataset.retGradAccum(i)` -> (accum_iter, accum_sum)) but the optimizer still steps -- and the
+    gradients are zeroed -- after EVERY batch (:96-100), so the extra step at a dialogue end (:102-106) runs on zeroed gradients:
+    torch's AdamW skips parameters whose .grad is None, hence that second step changes nothing but the scheduler call."""
+    iters = len(train_dataloader)
+    total_loss_train = 0.0
+    for batch_idx, (train_input, train_label) in enumerate(train_dataloader):
+        accum_iter, accum_sum = train_dataloader.dataset.retGradAccum(i=batch_idx)
+        loss = get_statistics(train_input, train_label, model, PREFormer, criterion, Metric, check="train", epoch=epoch) / accum_iter
+        total_loss_train += loss.item()
+        loss.backward()
+        if stepper.reducer is not None:
+            stepper.reducer.finish()
+        stepper.update()
+        scheduler.step(epoch + batch_idx / iters)
+        if ((batch_idx + 1) % accum_sum == 0) or (batch_idx + 1 == iters):
+            stepper.update()                     # no gradients left: a no-op, as in the reference
+            scheduler.step(epoch + batch_idx / iters)
+        if ((batch_idx + 1) % log_val == 0) or (batch_idx + 1 == iters):
+            log(Metric, total_loss_train / iters, "train")
+            val_loss = validate(val_dataloader, model, PREFormer, criterion, Metric, name="val")
+            prev_val_loss, stop = _save_if_better(val_loss, prev_val_loss, model, PREFormer, stepper, criterion, scheduler, epoch, batch_idx, path, log_val, patience)
+            if stop:
+                break
+    return prev_val_loss
+
+
+def one_epoch(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, epoch_switch, patience, Metric, prev_val_loss,
+              path=None, log_val=2400):
+    """reference :133-144: alternate the two loops by epoch parity, then reload the best checkpoint of the run (:143)."""
+    loop = not_grad_accum if (epoch % epoch_switch == 0 or not hasattr(train_dataloader.dataset, "retGradAccum")) else grad_accum
+    prev_val_loss = loop(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val, path)
+    if path is not None and os.path.exists(checkpoint_file(path)):
+        load_model(model, PREFormer, stepper.opt, criterion, path)
+    return prev_val_loss
 
 
 def train_tav_network(model, PREFormer, train_dataloader, val_dataloader, criterion, learning_rate, epochs, weight_decay, T_max, Metric, patience, clip,
-                      epoch_switch, checkpoint=None):
+                      epoch_switch, checkpoint=None, path=None, log_val=2400):
+    """reference :147-164.  `path` (None = keep nothing on disk) replaces the cluster path hard-coded at :137; `checkpoint` is a loaded
+    best.pt dict whose optimizer / scheduler state resumes the run (:152-155)."""
     stepper = TrainStep(model, PREFormer, criterion, lr=learning_rate, weight_decay=weight_decay, clip=clip)
     scheduler = CosineWarmRestarts(stepper.opt, T_0=T_max)
     prev_val_loss = 100
+    if checkpoint is not None:
+        stepper.opt.load_state_dict(checkpoint["optimizer_state_dict"])
+        sched = checkpoint.get("scheduler_state_dict", checkpoint.get("scheduler"))      # the reference saves 'scheduler' (:223) and reads 'scheduler_state_dict' (:155)
+        if sched is not None:
+            scheduler.load_state_dict(sched)
     for epoch_num in range(epochs):
         if wandb is not None and getattr(wandb, "run", None) is not None:
             wandb.log({"epoch": epoch_num, "learning_rate": scheduler.get_last_lr()[0]})
         stepper.opt.zero_grad()
         prev_val_loss = one_epoch(epoch_num, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, epoch_switch, patience,
-                                  Metric, prev_val_loss)
+                                  Metric, prev_val_loss, path, log_val)
         if PATIENCE_ITER == patience:
             return model, PREFormer
     return model, PREFormer

@@ -1,6 +1,7 @@
 """Drop-in for the parts of the reference's utils/global_functions.py that the TAV path touches:
 NewCrossEntropyLoss (:51-83), MySampler (:21-49), arg_parse (:260-297, same flag names) and a dependency-free Metrics
 (the reference wraps torchmetrics, :114-188, which is outside the hot path and not installed here)."""
+import os
 from argparse import ArgumentParser
 
 import torch
@@ -59,6 +60,54 @@ class NewCrossEntropyLoss(nn.Module):
         if epoch % self.epoch_switch == 0:
             return self.normalCEL(logits, target)
         return self.weightedCEL(logits, target)
+
+
+def _run_names():
+    """(project, sweep_id, run name) of the active wandb run, as the reference's checkpoint path uses them (:203-226); fixed names offline."""
+    try:
+        import wandb
+        run = getattr(wandb, "run", None)
+        if run is not None:
+            return str(run.project), str(run.sweep_id), str(run.name)
+    except Exception:
+        pass
+    return "TAV_Train", "local", "run"
+
+
+def checkpoint_file(path):
+    return os.path.join(path, *_run_names(), "best.pt")
+
+
+def save_model(model, PREFormer, optimizer, criterion, scheduler, epoch, step, path, log_val):
+    """reference :199-236: best.pt = {'epoch', 'step', 'model_state_dict', 'optimizer_state_dict', 'loss', 'scheduler', ['PREFormer']}
+    under <path>/<project>/<sweep>/<run>/ (path: no trailing slash)."""
+    f = checkpoint_file(path)
+    os.makedirs(os.path.dirname(f), exist_ok=True)
+    torch.save({"epoch": epoch, "step": step, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                "loss": criterion.state_dict() if criterion is not None else {}, "scheduler": scheduler.state_dict() if scheduler is not None else {},
+                **({"PREFormer": PREFormer.state_dict()} if PREFormer is not None else {})}, f)
+    return f
+
+
+def load_model(model, PREFormer, optimizer, criterion, path, remap=True):
+    """reference :238-258.  `optimizer` is refreshed in place (the reference builds a new AdamW over the same parameters and loads the saved state
+    into it).  remap=True passes the state dicts through models.tav.remap_reference_keys, so a checkpoint written by the reference itself
+    (transformers 4.2x key names) loads as well."""
+    from ..models.tav import remap_reference_keys
+    f = checkpoint_file(path)
+    checkpoint = torch.load(f, map_location="cpu", weights_only=False)
+    print(f"Current best model is on epoch {checkpoint['epoch']}, and step {checkpoint['step']} on path {f}", flush=True)
+    fix = remap_reference_keys if remap else (lambda d: d)
+    model.load_state_dict(fix(checkpoint["model_state_dict"]))
+    if PREFormer is not None:
+        PREFormer.load_state_dict(fix(checkpoint["PREFormer"]))
+    if optimizer is not None:
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    if criterion is not None and checkpoint.get("loss") is not None:
+        criterion.load_state_dict(checkpoint["loss"])
+    from .. import engine
+    engine.bump_weight_epoch()               # parameters changed: cached low-precision operand copies must refresh
+    return model, PREFormer, optimizer, criterion
 
 
 class Metrics:

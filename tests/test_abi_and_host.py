@@ -167,3 +167,146 @@ def test_sampler_schedule_metrics_flags():
     assert cm.tolist() == [[1, 0, 0], [0, 1, 0], [0, 1, 1]] and abs(acc - (1 + 1 + 0.5) / 3) < 1e-9
     args = arg_parse("x", ["-l", "0.001", "--batch_size", "4", "--clip", "2.0", "--preset", "B"])
     assert args.learning_rate == 0.001 and args.batch_size == 4 and args.clip == 2.0 and args.loss == "NewCrossEntropy" and args.T_max == 2
+
+
+# ---- checkpoint format and train-loop parity (host logic, CPU) -----------------------------------------
+def test_cosine_warm_restarts_matches_torch():
+    from tav_amd.train_model.tav_train import CosineWarmRestarts
+
+    class _Opt:
+        lr = 3e-4
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.AdamW([p], lr=3e-4)
+    ref = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(ref_opt, T_0=2)
+    mine = CosineWarmRestarts(_Opt(), T_0=2)
+    for e in (0.0, 0.25, 1.0, 1.9, 2.0, 3.5, 4.0):
+        ref.step(e)
+        mine.step(e)
+        assert abs(mine.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-12
+    sd = mine.state_dict()
+    assert {"T_0", "T_i", "T_mult", "eta_min", "T_cur", "base_lrs", "last_epoch", "_last_lr"} <= set(sd) and set(sd) <= set(ref.state_dict())
+    other = CosineWarmRestarts(_Opt(), T_0=7)
+    other.load_state_dict(ref.state_dict())                       # a scheduler state saved by the reference resumes here
+    assert other.T_0 == 2 and abs(other.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-12
+
+
+def test_fused_adamw_state_dict_is_torch_format():
+    from tav_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    ref = torch.optim.AdamW(ps, lr=1e-3, weight_decay=1e-2)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ref.step()
+    sd = ref.state_dict()
+    opt = FusedAdamW(ps, lr=5.0, weight_decay=0.5)
+    opt.load_state_dict(sd)                                       # torch checkpoint -> fused optimizer
+    assert opt.lr == 1e-3 and opt.weight_decay == 1e-2 and opt.step_count == 2
+    out = opt.state_dict()
+    assert out["param_groups"][0]["params"] == [0, 1] and set(out["state"]) == {0, 1}
+    for i in (0, 1):
+        assert torch.equal(out["state"][i]["exp_avg"], sd["state"][i]["exp_avg"]) and torch.equal(out["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(out["state"][i]["step"]) == 2.0
+    fresh = torch.optim.AdamW(ps, lr=1.0)
+    fresh.load_state_dict(out)                                    # and back: fused state -> torch.optim.AdamW
+    assert fresh.param_groups[0]["lr"] == 1e-3 and float(fresh.state[ps[0]]["step"]) == 2.0
+
+
+def test_best_pt_round_trip(tmp_path):
+    """save_model / load_model write and read the reference's best.pt layout (utils/global_functions.py:199-258), including a checkpoint
+    that carries transformers-4.2x VideoMAE key names."""
+    from tav_amd.models.tav import PreFormer, TAVForMAE
+    from tav_amd.optim import FusedAdamW
+    from tav_amd.train_model.tav_train import CosineWarmRestarts
+    from tav_amd.utils import global_functions as G
+    cfg = cfgmod.preset("B-tiny")
+    args = dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12)
+    torch.manual_seed(1)
+    model, pre = TAVForMAE(args, cfg), PreFormer(cfg)
+    crit = G.NewCrossEntropyLoss(torch.ones(7))
+    opt = FusedAdamW(list(model.parameters()) + list(pre.parameters()), lr=2e-5, weight_decay=1e-4)
+    sched = CosineWarmRestarts(opt, T_0=2)
+    sched.step(0.5)
+    f = G.save_model(model, pre, opt, crit, sched, 3, 17, str(tmp_path), 2400)
+    ck = torch.load(f, weights_only=False)
+    assert {"epoch", "step", "model_state_dict", "optimizer_state_dict", "loss", "scheduler", "PREFormer"} == set(ck) and ck["epoch"] == 3 and ck["step"] == 17
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    # rewrite the VideoMAE attention biases the way a 4.2x-era reference checkpoint names them, then reload through the remap
+    sd = ck["model_state_dict"]
+    for k in [k for k in sd if k.startswith("videomae.") and k.endswith(".attention.attention.query.bias")]:
+        base = k[: -len("query.bias")]
+        sd[base + "q_bias"] = sd.pop(k)
+        sd[base + "v_bias"] = sd.pop(base + "value.bias")
+        sd.pop(base + "key.bias")
+    torch.save(ck, f)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    opt.lr = 1.0
+    G.load_model(model, pre, opt, crit, str(tmp_path))
+    for k, v in model.state_dict().items():
+        if not k.endswith(".attention.attention.key.bias"):
+            assert torch.equal(v, want[k]), k
+    import math
+    assert abs(opt.lr - 2e-5 * (1 + math.cos(math.pi * 0.25)) / 2) < 1e-12      # the learning rate the scheduler had set when the checkpoint was written
+
+
+def test_grad_accum_loop_steps_like_the_reference(monkeypatch):
+    """train_model/tav_train.py:87-119: loss / dialogue length, an optimizer step after EVERY batch and a second (gradient-free) one at each
+    dialogue end; validation + best-checkpoint bookkeeping on the last batch."""
+    from tav_amd.train_model import tav_train as T
+
+    class Loss:
+        def __init__(self, v):
+            self.v = v
+
+        def __truediv__(self, d):
+            return Loss(self.v / d)
+
+        def item(self):
+            return self.v
+
+        def backward(self):
+            calls.append(("backward", self.v))
+
+    class Stepper:
+        reducer = None
+        opt = None
+
+        def update(self):
+            calls.append(("update",))
+
+    class Sched:
+        def step(self, e):
+            calls.append(("sched", round(e, 4)))
+
+    class DS:
+        grad, grad_sum, ctr = [2, 3], [2, 5], 0              # two dialogues: 2 and 3 utterances (utils/data_loaders.py:47-57)
+
+        def retGradAccum(self, i):
+            r, s = self.grad[self.ctr], self.grad_sum[self.ctr]
+            if i + 1 == self.grad_sum[self.ctr]:
+                self.ctr += 1
+            if self.ctr == len(self.grad):
+                self.ctr = 0
+            return r, s
+
+    class DL(list):
+        dataset = DS()
+    calls = []
+    dl = DL([(None, None)] * 5)
+    monkeypatch.setattr(T, "get_statistics", lambda *a, **k: Loss(6.0))
+    monkeypatch.setattr(T, "validate", lambda *a, **k: 0.5)
+    monkeypatch.setattr(T, "log", lambda *a, **k: None)
+    T.PATIENCE_ITER = 0
+    best = T.grad_accum(1, dl, None, None, None, None, Stepper(), Sched(), 10, None, 100, 2400, None)
+    assert best == 0.5
+    assert [c[1] for c in calls if c[0] == "backward"] == [3.0, 3.0, 2.0, 2.0, 2.0]
+    seq = [c[0] for c in calls]
+    # batch index 1 ends dialogue 1 (accum_sum = 2: (1+1) % 2 == 0), batch index 4 ends dialogue 2 ((4+1) % 5 == 0) and is the last one
+    assert seq == ["backward", "update", "sched",
+                   "backward", "update", "sched", "update", "sched",
+                   "backward", "update", "sched",
+                   "backward", "update", "sched",
+                   "backward", "update", "sched", "update", "sched"]

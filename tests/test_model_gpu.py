@@ -350,3 +350,46 @@ def test_rccl_reducer_single_rank(gpu, monkeypatch):
             assert abs(l0 - l1) / abs(l0) < 1e-4
             for k in g0:
                 assert rel(g0[k], g1[k]) < 2e-2, k
+
+
+def test_best_pt_resume_continues_bitwise(gpu, tmp_path):
+    """a run interrupted after two steps and resumed from best.pt (model, PreFormer, AdamW moments + step count) takes
+    the same third step as the uninterrupted run."""
+    from tav_amd.train_model.tav_train import CosineWarmRestarts, TrainStep
+    from tav_amd.utils import global_functions as G
+    cfg = C.preset("B-tiny")
+    runtime.set_precision("fp32")
+    inp, lab = synthetic.make_batch(cfg, 2, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")
+
+    def build():
+        torch.manual_seed(0)
+        pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+        synthetic.seeded_init_(pre, 1)
+        synthetic.seeded_init_(model, 2)
+        return pre.cuda(), model.cuda()
+
+    def steps(stepper, n):
+        for _ in range(n):
+            stepper.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4)
+            stepper.update()
+
+    crit = G.CrossEntropyLoss()
+    pre_a, model_a = build()
+    a = TrainStep(model_a, pre_a, crit, lr=1e-3, weight_decay=1e-2)
+    steps(a, 3)
+    pre_b, model_b = build()
+    b = TrainStep(model_b, pre_b, crit, lr=1e-3, weight_decay=1e-2)
+    steps(b, 2)
+    G.save_model(model_b, pre_b, b.opt, crit, CosineWarmRestarts(b.opt, 2), 0, 1, str(tmp_path), 2400)
+    pre_c, model_c = build()
+    c = TrainStep(model_c, pre_c, crit, lr=7.0, weight_decay=0.0)
+    G.load_model(model_c, pre_c, c.opt, crit, str(tmp_path))
+    assert c.opt.step_count == 2 and c.opt.lr == 1e-3
+    steps(c, 1)
+    worst = 0.0
+    for (k, pa), (_, pc) in zip(list(model_a.named_parameters()) + list(pre_a.named_parameters()), list(model_c.named_parameters()) + list(pre_c.named_parameters())):
+        if "embedding" in k:
+            worst = max(worst, rel(pc, pa))
+        else:
+            assert torch.equal(pa, pc), k
+    assert worst < 1e-5
