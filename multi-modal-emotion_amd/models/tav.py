@@ -289,3 +289,42 @@ def collate_batch(batch, check):
     audio_features = {"audio_features": audio, "attention_mask": amask}
     visual = {"visual_embeds": torch.stack(vids), "attention_mask": vid_mask}
     return [text, audio_features, visual], torch.Tensor(np.array(labels))
+
+
+def sample_video_mask(B, ntok, n_true=None, device="cpu", generator=None):
+    """Video token mask of collate_batch (reference :206-217) built ON THE DEVICE without a host round trip: True marks the tokens the
+    fusion stack sees and the video encoder drops.  The reference draws True w.p. 1/15 per token (a Binomial(ntok, 1/15) count per row)
+    and then patches the TOTAL to a multiple of the batch size; rows of unequal count make `reshape(b, -1, 768)` mix utterances, so
+    -- like collate_batch above -- every row gets the same count here, n_true (default round(ntok / 15): the reference's mean),
+    chosen uniformly at random: the n_true smallest of ntok i.i.d. uniforms per row."""
+    k = int(round(ntok / 15)) if n_true is None else int(n_true)
+    r = torch.rand(B, ntok, device=device, generator=generator)
+    idx = r.topk(k, dim=1, largest=False).indices
+    return torch.zeros(B, ntok, dtype=torch.bool, device=device).scatter_(1, idx, True)
+
+
+def collate_batch_device(batch, check, device="cuda", n_visual_true=None, generator=None):
+    """collate_batch with the tensor work on `device`: items are decoded utterances as for collate_batch; every
+    tensor is shipped once (non-blocking) and padding, the audio length mask (reference :225-228) and the video token mask are built
+    there, sync-free: nothing in the step reads them back (PreFormer / TAVForMAE take `n_visual_true` instead of counting)."""
+    texts, masks, speech, vids, labels = [], [], [], [], []
+    for (inp, label) in batch:
+        texts.append(torch.as_tensor(inp[0]["input_ids"]).reshape(-1))
+        masks.append(torch.as_tensor(inp[0]["attention_mask"]).reshape(-1).float())
+        speech.append(torch.as_tensor(inp[1]).float().reshape(-1))
+        v = torch.as_tensor(inp[2]).float()
+        vids.append(v if v.shape[1] == 3 else v.permute(1, 0, 2, 3))
+        labels.append(float(label))
+    B = len(labels)
+    dev = torch.device(device)
+    lens = torch.tensor([len(s) for s in speech])
+    T = int(lens.max())
+    audio = torch.nn.utils.rnn.pad_sequence([s.to(dev, non_blocking=True) for s in speech], batch_first=True)          # zero padding, reference :228
+    amask = (torch.arange(T, device=dev)[None, :] < lens.to(dev, non_blocking=True)[:, None]).float()
+    video = torch.stack([v.to(dev, non_blocking=True) for v in vids])
+    ntok = (video.shape[1] // 2) * (video.shape[3] // 16) * (video.shape[4] // 16)
+    vid_mask = sample_video_mask(B, ntok, n_visual_true, dev, generator)
+    text = {"input_ids": torch.stack(texts).long().to(dev, non_blocking=True), "attention_mask": torch.stack(masks).to(dev, non_blocking=True)}
+    return [text, {"audio_features": audio, "attention_mask": amask}, {"visual_embeds": video, "attention_mask": vid_mask}], \
+        torch.tensor(labels, dtype=torch.float32).to(dev, non_blocking=True)
+

@@ -310,3 +310,23 @@ def test_grad_accum_loop_steps_like_the_reference(monkeypatch):
                    "backward", "update", "sched",
                    "backward", "update", "sched",
                    "backward", "update", "sched", "update", "sched"]
+
+
+def test_collate_batch_device_contract():
+    """the device-side collate yields the same contract as collate_batch (shapes, dtypes, zero padding, 0/1 audio mask
+    matching the lengths) with exactly n_visual_true True tokens per row (pure torch: checked on the CPU device here)."""
+    from tav_amd.models.tav import collate_batch, collate_batch_device, sample_video_mask
+    torch.manual_seed(0)
+    lens = [700, 1000, 400]
+    batch = [([{"input_ids": torch.randint(3, 100, (12,)), "attention_mask": torch.ones(12)}, torch.randn(n), torch.randn(16, 3, 32, 32)], i % 7)
+             for i, n in enumerate(lens)]
+    (t, a, v), lab = collate_batch_device(batch, "train", device="cpu", n_visual_true=4)
+    (t0, a0, v0), lab0 = collate_batch(batch, "train")
+    assert t["input_ids"].dtype == torch.int64 and torch.equal(t["input_ids"], t0["input_ids"]) and torch.equal(t["attention_mask"], t0["attention_mask"])
+    assert torch.equal(a["audio_features"], a0["audio_features"]) and torch.equal(a["attention_mask"], a0["attention_mask"])
+    assert a["attention_mask"].sum(1).tolist() == [float(n) for n in lens] and float(a["audio_features"][2, 400:].abs().max()) == 0.0
+    assert torch.equal(v["visual_embeds"], v0["visual_embeds"]) and v["attention_mask"].dtype == torch.bool and v["attention_mask"].shape == v0["attention_mask"].shape
+    assert v["attention_mask"].sum(1).tolist() == [4, 4, 4]
+    assert torch.equal(lab, lab0) and lab.dtype == torch.float32
+    m = sample_video_mask(64, 1568)
+    assert m.sum(1).unique().tolist() == [105] and 0.2 < m[:, :784].float().mean() * 15 < 2.0       # round(1568/15) per row, spread over the row
