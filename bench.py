@@ -167,6 +167,7 @@ def main():
         # captured: G1 = forward + loss + backward + pack gradients into their buckets, then one all-reduce (mean) per bucket on the
         # work stream, then G2 = clip_grad_norm_ + AdamW reading the reduced buckets.  The host only enqueues ~35 collectives per
         # step (the eager hook-based path -- all-reduce overlapped with the backward on a side stream -- is host bound at ~44 ms/step).
+        g1 = g2 = static_loss = None
         try:
             from tav_amd import engine
             torch.cuda.synchronize()
@@ -181,6 +182,16 @@ def main():
                 stepper.reducer.pack_all()
             with torch.cuda.graph(g2, stream=work_stream, pool=g1.pool()):
                 stepper.update()
+            captured = True
+        except Exception as e:
+            import traceback
+            log(f"[rank {rank}] graph capture failed ({type(e).__name__})\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
+            captured = False
+            torch.cuda.synchronize()
+        # every rank must issue the same sequence of collectives: agree BEFORE the first replay (no collective was issued since the barrier)
+        ok = torch.tensor([1.0 if captured else 0.0], device=dev)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if ok.item() > 0.5:
             graph = (g1, g2)
 
             def one_step():                                  # noqa: F811
@@ -192,12 +203,11 @@ def main():
                 one_step()
             torch.cuda.synchronize()
             log(f"[rank {rank}] step captured into two hipGraphs around {len(stepper.reducer.buckets)} eager all-reduces")
-        except Exception as e:
-            import traceback
-            log(f"[rank {rank}] graph capture failed ({type(e).__name__}); falling back to eager\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
+        else:
+            log(f"[rank {rank}] falling back to eager launches (hook-mode all-reduce) on all ranks")
+            stepper.opt.zero_grad()
             stepper.reducer.set_manual(False)
             graph, one_step = None, eager_step
-            torch.cuda.synchronize()
     elif args.graph and world == 1:
         try:
             from tav_amd import engine

@@ -383,6 +383,12 @@ def all_checks():
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=64, nh=1))
         out.append(lambda d=dtype: check_attention(d, 2, B=1, S=481, nh=12))
         out.append(lambda d=dtype: check_attention(d, 2, B=2, S=481, nh=12, ref_style_mask=True))
+        # size extremes of the path: 1 token, the text model's longest sequence (514 positions -> 512 tokens, pre-softmax mask), the
+        # 32-frame video of BASELINE config 5 (3136 tokens before masking), 10 s audio (499 frames)
+        out.append(lambda d=dtype: check_attention(d, 0, B=2, S=1, nh=2))
+        out.append(lambda d=dtype: check_attention(d, 1, B=1, S=512, nh=2))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=3136, nh=1))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=499, nh=2))
         out.append(lambda d=dtype: check_layernorm(d))
         out.append(lambda d=dtype: check_layernorm(d, W=512, act=1))
         out.append(lambda d=dtype: check_layernorm(d, W=1024))
