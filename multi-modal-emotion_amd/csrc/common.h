@@ -129,15 +129,16 @@ template <> TAV_DEV uint4 acc_to_kfrag<float>(const f32x4* t) {
 TAV_DEV unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
 }
-// One wave instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_base + 16*l).
-// lds_base must be wave-uniform.  Issued from inline asm on purpose: hipcc would otherwise treat the DMA as a pending LDS
-// write and put `s_waitcnt vmcnt(0)` in front of every following ds_read, serialising load and compute.  The caller
-// waits with wait_vmcnt0() + a barrier before any wave reads the staged bytes.
-TAV_DEV void glds16(const void* gsrc, unsigned lds_base) {
+// One wave instruction: lane l copies the 16 bytes at (sbase + voff_l) to LDS byte (lds_base + 16*l).  sbase (64-bit) and lds_base
+// must be wave-uniform (SGPRs), voff is the lane's 32-bit byte offset: advancing a K-tile costs ONE v_add_u32 per instruction instead
+// of a 64-bit multiply-add chain.  Issued from inline asm on purpose: hipcc would otherwise treat the DMA as a pending LDS write and
+// put `s_waitcnt vmcnt(0)` in front of every following ds_read, serialising load and compute.  The caller waits with a counted
+// vmcnt (wait_vmcnt0() in the simplest case) + a barrier before any wave reads the staged bytes.
+TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
+                 : "v"(voff), "s"(sbase), "s"(lds_base)
                  : "memory");
 }
 // Values loaded from global memory BEFORE a loop and consumed inside it: hipcc's waitcnt pass cannot tell how many younger loads
@@ -146,15 +147,6 @@ TAV_DEV void glds16(const void* gsrc, unsigned lds_base) {
 // the output of an (empty) asm statement: the wait happens once, here, and the loop body carries none.
 TAV_DEV void settle(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 TAV_DEV void settle(float& v) { asm volatile("" : "+v"(v)); }
-// Same, with the source split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the per-K-tile
-// address update is then ONE v_add_u32 per instruction instead of a 64-bit multiply-add chain.
-TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_base)
-                 : "memory");
-}
 TAV_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- wave reductions ----------------------------------------------------------------------------
