@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256) void adamw_chunk_kernel(float* const* __restri
         for (; i + (U - 1) * 256 < n4; i += U * 256) {
             f32x4 w[U], a[U], s2[U], gr[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {                // every byte is touched exactly once per step: non-temporal both ways
                 const long j = 4 * (i + u * 256);
-                w[u] = *reinterpret_cast<f32x4*>(p + j); gr[u] = *reinterpret_cast<const f32x4*>(g + j);
-                a[u] = *reinterpret_cast<f32x4*>(ea + j); s2[u] = *reinterpret_cast<f32x4*>(es + j);
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + j)); gr[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + j));
+                a[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(ea + j)); s2[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(es + j));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void adamw_chunk_kernel(float* const* __restri
                     w[u][k] = wk; a[u][k] = ak; s2[u][k] = sk;
                 }
                 const long j = 4 * (i + u * 256);
-                *reinterpret_cast<f32x4*>(p + j) = w[u]; *reinterpret_cast<f32x4*>(ea + j) = a[u]; *reinterpret_cast<f32x4*>(es + j) = s2[u];
+                *reinterpret_cast<f32x4*>(p + j) = w[u];         // the updated weights are read again right away (operand casts): default policy
+                __builtin_nontemporal_store(a[u], reinterpret_cast<f32x4*>(ea + j)); __builtin_nontemporal_store(s2[u], reinterpret_cast<f32x4*>(es + j));
             }
         }
         for (; i < n4; i += 256) {

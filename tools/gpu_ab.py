@@ -97,3 +97,13 @@ if "ln" in what:          # LayerNorm backward (with dgamma/dbeta) at the four b
         dy = torch.randn(rows, 768, device=dev)
         lo, med = timeit(lambda: ops.ln_bwd(dy, x, g, bt, mean, rstd, want_f32=True, lp_dtype=torch.bfloat16))
         print(f"[{tag}] ln_bwd {name:7s} rows={rows:6d}: min {lo:6.1f} us  med {med:6.1f} us")
+if "adamw" in what:       # fused clip + AdamW over a BERT-base-like parameter list (110 M parameters)
+    from tav_amd.optim import FusedAdamW
+    shapes = [(30522, 768)] + [(768, 768)] * 48 + [(3072, 768)] * 12 + [(768, 3072)] * 12 + [(768,)] * 100 + [(3072,)] * 12
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.02) for s in shapes]
+    for p_ in ps:
+        p_.grad = torch.randn_like(p_) * 1e-3
+    opt = FusedAdamW(ps, lr=1e-4, weight_decay=1e-2)
+    n = sum(p_.numel() for p_ in ps)
+    lo, med = timeit(lambda: opt.clip_and_step(1.0), iters=20, reps=7)
+    print(f"[{tag}] clip+adamw {n / 1e6:.0f} M params: min {lo:7.1f} us  med {med:7.1f} us  {n * 32 / lo / 1e6:6.2f} TB/s (32 B/param incl. the norm pass)")
