@@ -760,6 +760,13 @@ static int check(const tav_attn_args* a, bool bwd) {
     const int pk = a->dtype == TAV_BF16 ? 8 : 4;
     if (a->ld_q % pk || a->ld_k % pk || a->ld_v % pk || a->ld_o % 4) return TAV_ERR_ALIGN;
     if (a->ld_q < a->nheads * 64 || a->ld_k < a->nheads * 64 || a->ld_v < a->nheads * 64 || a->ld_o < a->nheads * 64) return TAV_ERR_SHAPE;
+    {   // the streamed tiles are addressed with 32-bit byte offsets inside one batch entry's slice
+        const int64_t es = a->dtype == TAV_BF16 ? 2 : 4;
+        int64_t ld = a->ld_q > a->ld_k ? a->ld_q : a->ld_k;
+        ld = ld > a->ld_v ? ld : a->ld_v;
+        if (bwd && a->ld_do > ld) ld = a->ld_do;
+        if ((a->S + 64) * ld * es >= (1ll << 32)) return TAV_ERR_SHAPE;
+    }
     if (bwd) {
         if (!a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return TAV_ERR_NULL;
         if (a->ld_do % pk || a->ld_dq % 4 || a->ld_dk % 4 || a->ld_dv % 4) return TAV_ERR_ALIGN;
