@@ -258,8 +258,18 @@ def main():
         flops, secs, launches = ops.profile_stop()
         runtime.multistream[0] = True
         ach = flops / secs / 1e12
+        # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/r01_pmc/traffic_per_launch.json: 2 x FETCH + WRITE, averaged
+        # over every gemm_nt launch), next to the algorithmic minimum (operands + output once) counted live
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic_per_launch.json")) as f:
+                traffic = json.load(f)["families"]["gemm_nt_kernel"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            pass
         roof = {"kernel": "tav::gemm_nt_kernel<bf16,*>", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": launches // 2,
+                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(getattr(ops.profile_stop, "algorithmic_bytes", 0.0) / max(launches, 1)), "launches_per_step": launches // 2,
                 "avg_launch_us": round(secs / launches * 1e6, 2), "serial_ms_per_step": round(secs / 2 * 1e3, 3)}
 
     cpu_ref = None

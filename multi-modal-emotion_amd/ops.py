@@ -39,8 +39,9 @@ def profile_stop():
     """-> (algorithmic FLOPs, seconds inside the kernels, launches) since profile_start()."""
     global _prof
     torch.cuda.synchronize()
-    ev, _prof = _prof["ev"], None
+    ev, nbytes, _prof = _prof["ev"], _prof.get("bytes", 0.0), None
     secs = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) * 1e-3
+    profile_stop.algorithmic_bytes = nbytes          # operands + output once each (the minimum the launches could move)
     return sum(f for _, _, f in ev), secs, len(ev)
 
 
@@ -81,7 +82,9 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
         e0.record()
         check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
         e1.record()
-        _prof["ev"].append((e0, e1, 2.0 * M * N * K * max(nzb, 1) * max(nzg, 1)))
+        nz = max(nzb, 1) * max(nzg, 1)
+        _prof["ev"].append((e0, e1, 2.0 * M * N * K * nz))
+        _prof["bytes"] = _prof.get("bytes", 0.0) + nz * ((M * K + N * K) * a.element_size() + M * N * (4 if out_dtype == torch.float32 else 2))
     else:
         check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return (out, pre) if want_pre else out
