@@ -57,7 +57,7 @@ typedef struct tav_gemm_nt_args {
     int32_t act;            /* 0 none, 1 exact-erf GELU */
     int32_t accumulate;
     float alpha;
-    int32_t tile_m_hint;    /* 0 = let the library choose; 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128 (8 waves, bf16 operands) (tuning / tests) */
+    int32_t tile_m_hint;    /* 0 = let the library choose; bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands); bits 5-7: LDS ring depth 2-4 (tuning / tests) */
 } tav_gemm_nt_args;
 int tav_gemm_nt(const tav_gemm_nt_args* args, void* stream);
 

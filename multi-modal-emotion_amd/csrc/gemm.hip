@@ -57,11 +57,11 @@ TAV_DEV int xcd_remap(int id, int total) {
 //    (85 FLOP/B, one 8-wave workgroup per CU) is faster wherever its coarser tile grid still fills the chip;
 //  * the tile count must divide well over the 256 CUs (M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle in
 //    the last round, 732 tiles of 96 rows do not) and small-M problems must still produce enough workgroups.
-template <typename T, typename TO, int TM, int NST, int NW>
+template <typename T, typename TO, int TM, int NST, int NW, int TNW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
-    constexpr int BM = 8 * TM * NW, BN = 128;
-    constexpr int PB = 16 / NW;                           // DMA pieces of the B image per wave (the A image: TM per wave)
+    constexpr int BM = 8 * TM * NW, BN = 32 * TNW;        // TNW = 16-column MFMA tiles per wave along N (4: BN = 128, 8: BN = 256)
+    constexpr int PB = BN / 8 / NW;                       // DMA pieces of the B image per wave (the A image: TM per wave)
     constexpr int NP = TM + PB;                           // DMA pieces per wave per K-tile
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes per K-tile image
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,22 +112,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
         else glds16_s(Bb, gb[pc - TM] + ko, ldsB + buf * TILE_B + (pc - TM) * 1024);
     };
 
-    f32x4 acc[4][TM];  // [tn][tm]
+    f32x4 acc[TNW][TM];  // [tn][tm]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TNW; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / 128;
-    int off_a[2][TM], off_b[2][4];
+    int off_a[2][TM], off_b[2][TNW];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) { const int r = wm * 16 * TM + t * 16 + i; off_a[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const int r = wn * 64 + t * 16 + i; off_b[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
+        for (int t = 0; t < TNW; ++t) { const int r = wn * 16 * TNW + t * 16 + i; off_b[s2][t] = r * 128 + swz(r, 4 * s2 + g) * 16; }
     }
-    uint4 fa0[TM], fb0[4], fa1[TM], fb1[4];
+    uint4 fa0[TM], fb0[TNW], fa1[TM], fb1[TNW];
     // One K-tile: wait for the image, read both fragment sets, then the MFMAs.  The TM+4 DMA pieces of the NEXT image are
     // issued between the MFMA groups of the first fragment set (a DMA costs the issuing wave 60-180 cycles of issue time;
     // spread out they run under the matrix pipe, and the second set's MFMAs give them time to land before the next wait).
@@ -151,21 +151,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]);
+        for (int t = 0; t < TNW; ++t) fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]);
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
+        for (int t = 0; t < TNW; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
         }
         __builtin_amdgcn_sched_barrier(0);                  // keep all 16 fragment reads in flight ahead of the MFMAs
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
+        for (int tn = 0; tn < TNW; ++tn) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
             if constexpr (decltype(prefetch)::value) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pc = tn * NP / 4; pc < (tn + 1) * NP / 4; ++pc) {
+                for (int pc = tn * NP / TNW; pc < (tn + 1) * NP / TNW; ++pc) {
 #ifdef TAV_ABL_NODMA
                     if (kt < 0)
 #endif
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
             }
         }
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
     };
@@ -195,42 +195,56 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     // per 16x16 tile, 16-B chunks XOR-swizzled with the row so both the writes and the row-major reads are conflict free -- and
     // the epilogue runs row-major: 32 threads per row, 16 B per thread, every global access a full 512-B (f32) / 256-B (bf16) run.
     __syncthreads();                                       // all waves finished reading the operand images
-    float* sC = reinterpret_cast<float*>(smem);            // [BM][128] f32 = BM*512 B  (<= staging size for TM = 2,3,4)
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int r = wm * 16 * TM + tm * 16 + i;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int ch = wn * 16 + tn * 4 + g;
-            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4)) = acc[tn][tm];
-        }
-    }
-    __syncthreads();
+    float* sC = reinterpret_cast<float*>(smem);            // [EP_ROWS][BN] f32 inside the (now idle) staging buffers
+    constexpr int ROWB_C = BN * 4;                          // bytes per staged row
+    constexpr int CPR = BN / 4;                             // 16-B chunks per row (32 / 64)
+    constexpr int LDS_BYTES = NST * (TILE_A + TILE_B);
+    constexpr int EP_ROWS = (LDS_BYTES / ROWB_C) < BM ? (LDS_BYTES / ROWB_C) / (16 * TM) * (16 * TM) : BM;   // rows per pass: whole wave-row bands
+    constexpr int NPASS = BM / EP_ROWS;
+    static_assert(EP_ROWS >= 16 * TM && BM % EP_ROWS == 0, "epilogue staging");
     const long coff = zb * p.c_zb + zg * p.c_zg;
     TO* C = reinterpret_cast<TO*>(p.C) + coff;
     TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
     const T* Gin = p.gelu_in ? reinterpret_cast<const T*>(p.gelu_in) + coff : nullptr;
     const float* R = p.resid ? p.resid + coff : nullptr;
-    const int ch = tid & 31, rr = tid >> 5;                // this thread's 16-B column chunk (fixed) and row within a pass (2*NW rows)
+    const int ch = tid % CPR, rr = tid / CPR;              // this thread's 16-B column chunk (fixed) and row within an iteration
+    constexpr int RPI = 64 * NW / CPR;                      // rows per iteration of the store loop
     const int n = n0 + 4 * ch;
-    if (n < p.N) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
-#pragma unroll 4
-        for (int r = rr; r < BM; r += 2 * NW) {
-            const int m = m0 + r;
-            if (m >= p.M) break;
-            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * 512 + ((ch ^ (r & 31)) << 4));
-            v = v * p.alpha + bv;
-            if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
-            if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
-            if (Gin) {
-                f32x4 u = ld4(Gin + (long)m * p.ld_gelu + n);
-                v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N && p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int row_lo = pass * EP_ROWS;
+        if (pass) __syncthreads();                          // the previous pass has been stored
+        if (wm * 16 * TM >= row_lo && wm * 16 * TM < row_lo + EP_ROWS) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int r = wm * 16 * TM + tm * 16 + i - row_lo;
+#pragma unroll
+                for (int tn = 0; tn < TNW; ++tn) {
+                    const int cc = wn * 4 * TNW + tn * 4 + g;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sC) + r * ROWB_C + ((cc ^ (r & 31)) << 4)) = acc[tn][tm];
+                }
             }
-            if (R) v += ld4(R + (long)m * p.ld_resid + n);
-            if (p.accumulate) v += ld4(C + (long)m * p.ldc + n);
-            st4(C + (long)m * p.ldc + n, v);
+        }
+        __syncthreads();
+        if (n < p.N) {
+#pragma unroll 4
+            for (int r = rr; r < EP_ROWS; r += RPI) {
+                const int m = m0 + row_lo + r;
+                if (m >= p.M) break;
+                f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
+                v = v * p.alpha + bv;
+                if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
+                if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
+                if (Gin) {
+                    f32x4 u = ld4(Gin + (long)m * p.ld_gelu + n);
+                    v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
+                }
+                if (R) v += ld4(R + (long)m * p.ld_resid + n);
+                if (p.accumulate) v += ld4(C + (long)m * p.ldc + n);
+                st4(C + (long)m * p.ldc + n, v);
+            }
         }
     }
 }
@@ -516,7 +530,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 using namespace tav;
 
 // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-static int nt_pick_tile(int M, int tiles_n, int nz, bool bf16_in) {
+static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in) {
+    const int tiles_n = (N + 127) / 128;
     int tm = 4;
     double best = 1e30;
     for (int c = 4; c >= 2; --c) {
@@ -524,7 +539,20 @@ static int nt_pick_tile(int M, int tiles_n, int nz, bool bf16_in) {
         const double cost = (double)((tiles + 255) / 256) * (c + 0.8);
         if (cost < best - 1e-9) { best = cost; tm = c; }
     }
-    (void)bf16_in;
+    // 256x256 (8 waves, one workgroup per CU) against the 128-wide winner, in microseconds: rounds x (K-tiles x time per K-tile + prologue
+    // and epilogue), constants fitted to the tile sweep of tools/gpu_ab.py (they reproduce its timings within ~5 %).  The big tile
+    // moves half the bytes per FLOP through LDS (1.30 PFLOP/s at 4096^3 against 1.15) but its grid is 4x coarser.
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("TAV_NT_BIG"); big = e ? atoi(e) : 1; }
+    if (big && bf16_in && M >= 256 && N >= 256) {
+        static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.62, 0.80, 0.94}, fix[5] = {0, 0, 3.0, 3.5, 4.0};
+        const double nk = (double)K / 64.0;
+        const long t_small = (long)((M + 32 * tm - 1) / (32 * tm)) * tiles_n * nz;
+        const long t_big = (long)((M + 255) / 256) * ((N + 255) / 256) * nz;
+        const double us_small = (double)((long)((t_small + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm]);
+        const double us_big = (double)((t_big + 255) / 256) * (nk * 1.65 + 8.0);
+        if (us_big < 0.93 * us_small) tm = 16;
+    }
     return tm;
 }
 
@@ -552,41 +580,44 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
     p.tiles_n = (p.N + 127) / 128;
     // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-    int tm = a->tile_m_hint & 15;                            // 2/3/4: 64/96/128-row tiles (4 waves); 8: 256-row tile (8 waves)
-    int nst = (a->tile_m_hint >> 4) & 15;                    // tuning: LDS ring depth 2..4 (0 = let the library choose)
-    if (a->in_dtype != TAV_BF16 && tm == 8) tm = 4;
-    if (tm != 8 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.tiles_n, nzb * p.nzg, a->in_dtype == TAV_BF16);
-    const int bm = tm == 8 ? 256 : 32 * tm;
+    int tm = a->tile_m_hint & 31;                            // 2/3/4: 64/96/128 x 128 tiles (4 waves); 8: 256 x 128, 16: 256 x 256 (8 waves)
+    int nst = (a->tile_m_hint >> 5) & 7;                     // tuning: LDS ring depth 2..4 (0 = let the library choose)
+    if (a->in_dtype != TAV_BF16 && (tm == 8 || tm == 16)) tm = 4;
+    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K, nzb * p.nzg, a->in_dtype == TAV_BF16);
+    const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
     p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + bn - 1) / bn;
     const long wgs = (long)p.tiles_m * p.tiles_n * nzb * p.nzg;
     // Ring depth.  Large grids run two workgroups per CU and are bound by the L2->LDS intake, where depth changes nothing: 2.
     // A grid of at most one workgroup per CU (the text / audio / fusion branches' N = 768 GEMMs) is LATENCY bound instead -- a lone
     // workgroup waits out every DMA round trip -- and has the whole LDS to itself: 4 buffers (3 tiles in flight).
     if (tm == 8) nst = 3;
+    else if (tm == 16) nst = 2;
     else if (nst < 2 || nst > 4) nst = (wgs <= 256 && a->in_dtype == TAV_BF16) ? 4 : 2;
     if (a->in_dtype != TAV_BF16) nst = 2;
-    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm == 8 ? 512 : 256);
-    const size_t lds = (size_t)nst * (bm + 128) * 128;       // 8 waves: 3 x 48 KB (the f32 epilogue tile of 256 x 128 needs 128 KB of it)
-#define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                              \
-    do {                                                                                                          \
-        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4>), grid, block, lds, stream, p);         \
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, NS, 4>), grid, block, lds, stream, p);    \
-        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, NS, 4>), grid, block, lds, stream, p);                 \
+    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
+    const size_t lds = (size_t)nst * (bm + bn) * 128;        // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
+#define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                                 \
+    do {                                                                                                             \
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4, 4>), grid, block, lds, stream, p);         \
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, NS, 4, 4>), grid, block, lds, stream, p);    \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, NS, 4, 4>), grid, block, lds, stream, p);                 \
     } while (0)
-#define TAV_NT_LAUNCH(TT, TOO)                                                                                    \
-    do {                                                                                                          \
-        if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8>), grid, block, lds, stream, p);          \
-        else if (nst == 4) TAV_NT_LAUNCH_S(TT, TOO, 4);                                                            \
-        else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                            \
-        else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                          \
+#define TAV_NT_LAUNCH(TT, TOO)                                                                                       \
+    do {                                                                                                             \
+        if (tm == 16) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 2, 8, 8>), grid, block, lds, stream, p);         \
+        else if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8, 4>), grid, block, lds, stream, p);     \
+        else if (nst == 4) TAV_NT_LAUNCH_S(TT, TOO, 4);                                                               \
+        else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                               \
+        else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                             \
     } while (0)
     if (a->in_dtype == TAV_BF16) {
         if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
         else TAV_NT_LAUNCH(bf16, float);
     } else {
-        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4>), grid, block, lds, stream, p);
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4>), grid, block, lds, stream, p);
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4, 4>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4, 4>), grid, block, lds, stream, p);
     }
 #undef TAV_NT_LAUNCH
 #undef TAV_NT_LAUNCH_S

@@ -371,6 +371,11 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=700, N=768, K=64, tile_m=8, out_f32=True))
             out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=8))
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=8))
+            # 8-wave 256x256 tile, two-pass epilogue: ragged M / N, short and long K, every epilogue flavour
+            out.append(lambda d=dtype: check_gemm_nt(d, M=333, N=384, K=256, tile_m=16))
+            out.append(lambda d=dtype: check_gemm_nt(d, M=700, N=768, K=64, tile_m=16, out_f32=True))
+            out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=16))
+            out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_tn(d))
         out.append(lambda d=dtype: check_gemm_tn(d, M=249, N1=768, N2=512, nbatch=3))

@@ -63,7 +63,7 @@ if "tn" in what:
         a, b = rnd(M, N1), rnd(M, N2)
         lo, med = timeit(lambda: ops.gemm_tn(a, b))
         print(f"[{tag}] gemm_tn {name:12s} M={M:6d} N1={N1:5d} N2={N2:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N1 * N2 / lo / 1e6:7.1f} TF")
-if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/128 x 128 with 4 waves, 8 = 256 x 128 with 8 waves)
+if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/128 x 128 with 4 waves, 8 = 256 x 128 and 16 = 256 x 256 with 8 waves)
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
                             ("video ffn2", B * 1464, 768, 3072), ("video dffn1", B * 1464, 768, 3072), ("video dqkv", B * 1464, 768, 2304),
                             ("fusion qkv", B * 481, 2304, 768), ("fusion ffn1", B * 481, 3072, 768), ("audio ffn1", B * 249, 3072, 768),
@@ -71,7 +71,7 @@ if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/12
         a, b = rnd(M, K), rnd(N, K)
         bias = torch.randn(N, device=dev)
         row = []
-        for tm in (0, 2, 3, 4, 8):
+        for tm in (0, 2, 3, 4, 8, 16):
             lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm), iters=30, reps=5)
             row.append(f"tm{tm} {lo:6.1f}")
         print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: " + "  ".join(row) + "  us")
@@ -86,7 +86,7 @@ if "ring" in what:        # small-grid NT GEMMs (text / audio / fusion shapes): 
         row.append(f"auto {lo:5.1f}")
         for tm in (2, 3, 4):
             for nst in (2, 3, 4):
-                lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm + 16 * nst, out_dtype=torch.float32 if N == 768 else None), iters=30, reps=5)
+                lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm + 32 * nst, out_dtype=torch.float32 if N == 768 else None), iters=30, reps=5)
                 row.append(f"tm{tm}s{nst} {lo:5.1f}")
         print(f"[{tag}] gemm_nt {name:11s} M={M:5d} N={N:4d} K={K:4d}: " + " ".join(row))
 if "ln" in what:          # LayerNorm backward (with dgamma/dbeta) at the four branch sizes
