@@ -246,7 +246,8 @@ def main():
     log(f"[rank {rank}] timed region: {elapsed / args.steps * 1e3:.2f} ms/step, loss {final_loss:.5f}")
 
     roof = None
-    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
+    if not args.no_roofline and args.dtype == "bf16":
+        # (every rank runs it: in hook mode these steps contain the gradient all-reduces, which must be matched by all ranks)
         # Instrumented pass: eager launches (a HIP event pair per GEMM), all branches on ONE stream so that every launch has the
         # device to itself -- the same condition rocprofv3's kernel trace measures (it serialises dispatches), which is what
         # profiles/*kernel_stats* must agree with.  In the timed region above the four branches overlap.
@@ -257,7 +258,8 @@ def main():
         torch.cuda.synchronize()
         flops, secs, launches = ops.profile_stop()
         runtime.multistream[0] = True
-        ach = flops / secs / 1e12
+        ach = flops / max(secs, 1e-9) / 1e12
+    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/r01_pmc/traffic_per_launch.json: 2 x FETCH + WRITE, averaged
         # over every gemm_nt launch), next to the algorithmic minimum (operands + output once) counted live
