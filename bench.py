@@ -265,6 +265,8 @@ def main():
         # over every gemm_nt launch), next to the algorithmic minimum (operands + output once) counted live
         traffic = None
         try:
+            if not (b == 8 and args.preset == "B"):
+                raise LookupError("the committed PMC summary was taken on the default workload only")
             with open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic_per_launch.json")) as f:
                 traffic = json.load(f)["families"]["gemm_nt_kernel"]["hbm_bytes_per_launch_corrected"]
         except Exception:
