@@ -13,7 +13,7 @@ out = []
 for (name, M, N, K) in [("square 4096", 4096, 4096, 4096), ("video ffn1", 11712, 3072, 768), ("video ffn2", 11712, 768, 3072)]:
     a = torch.randn(M, K, device="cuda").bfloat16()
     b = torch.randn(N, K, device="cuda").bfloat16()
-    for tm in (4, 8):
+    for tm in (4, 16):
         for _ in range(5):
             ops.gemm_nt(a, b, tile_m=tm)
         best = 1e9
