@@ -191,8 +191,13 @@ __global__ __launch_bounds__(128) void wn_colsum_partial_kernel(const float* __r
 __global__ void wn_colsum_final_kernel(const float* __restrict__ partial, float* out, int nblocks, int K, int do_sqrt) {
     const int k = threadIdx.x;
     if (k >= K) return;
-    float s = 0.f;
-    for (int i = 0; i < nblocks; ++i) s += partial[(long)i * K + k];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;            // up to 512 partial rows in one workgroup: four loads in flight, not a serial chain
+    int i = 0;
+    for (; i + 3 < nblocks; i += 4) {
+        s0 += partial[(long)i * K + k]; s1 += partial[(long)(i + 1) * K + k]; s2 += partial[(long)(i + 2) * K + k]; s3 += partial[(long)(i + 3) * K + k];
+    }
+    for (; i < nblocks; ++i) s0 += partial[(long)i * K + k];
+    const float s = (s0 + s1) + (s2 + s3);
     out[k] = do_sqrt ? sqrtf(s) : s;
 }
 // GEMM layouts for the grouped conv (H = G*Cg channels, K taps):

@@ -393,8 +393,11 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const float* const* __
 }
 __global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partials, long n, float* out) {
     __shared__ float red[256];
-    float a = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) a += partials[i];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;            // ~19 k partials in one workgroup: four loads in flight per thread
+    long i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) { a0 += partials[i]; a1 += partials[i + 256]; a2 += partials[i + 512]; a3 += partials[i + 768]; }
+    for (; i < n; i += 256) a0 += partials[i];
+    const float a = (a0 + a1) + (a2 + a3);
     red[threadIdx.x] = a;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
