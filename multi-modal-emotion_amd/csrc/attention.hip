@@ -385,18 +385,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 // delta[b][h][q] = sum_d dO[q][d] * (softmax(s) v)[q][d]   (mode 2 reads the o_soft copy, never o - corr)
 template <typename T, int MODE>
 __global__ void attn_bwd_delta_kernel(const AttnP p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;            // over B*S*nh, head fastest
+    // delta[b][head][s] = sum_d dO[b,s,head,d] * O[b,s,head,d] (O = the softmax-only part under mask mode 2).  16 lanes per (token, head):
+    // each lane multiplies 4 elements (one 8-B / 16-B load per tensor instead of a 2-B one) and the 16 partial sums meet in 4 DPP shuffles.
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long pair = gid >> 4;                              // (token, head) index, head fastest
+    const int q = (int)(gid & 15);
     const long total = (long)p.B * p.S * p.nh;
-    if (row >= total) return;
-    const int head = (int)(row % p.nh);
-    const long bs = row / p.nh;
+    const bool live = pair < total;
+    const long pr = live ? pair : total - 1;
+    const int head = (int)(pr % p.nh);
+    const long bs = pr / p.nh;
     const int b = (int)(bs / p.S), s = (int)(bs - (long)b * p.S);
     const T* osrc = reinterpret_cast<const T*>(MODE == 2 ? p.o_soft : p.o);
-    const float o = ET<T>::ld(osrc + bs * p.ld_o + head * 64 + lane);
-    const float d_o = ET<T>::ld(reinterpret_cast<const T*>(p.dout) + bs * p.ld_do + head * 64 + lane);
-    const float v = wave_sum(d_o * o);
-    if (lane == 0) p.delta[((long)b * p.nh + head) * p.S + s] = v;
+    const f32x4 o = ld4(osrc + bs * p.ld_o + head * 64 + 4 * q);
+    const f32x4 d = ld4(reinterpret_cast<const T*>(p.dout) + bs * p.ld_do + head * 64 + 4 * q);
+    float v = (o[0] * d[0] + o[1] * d[1]) + (o[2] * d[2] + o[3] * d[3]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (live && q == 0) p.delta[((long)b * p.nh + head) * p.S + s] = v;
 }
 
 // ================================================================================================= backward: dK, dV
@@ -792,7 +798,7 @@ template <typename T, int MODE> static int launch_fwd(const AttnP& p, hipStream_
 }
 template <typename T, int MODE> static int launch_bwd(const AttnP& p, hipStream_t st) {
     const long rows = (long)p.B * p.S * p.nh;
-    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, MODE>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, MODE>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, p);
     dim3 grid((p.S + 127) / 128, p.nh, p.B);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE>), grid, dim3(256), dkdv_lds<T>(), st, p);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE>), grid, dim3(256), dq_lds<T>(), st, p);
