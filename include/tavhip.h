@@ -217,12 +217,14 @@ int tav_scatter_add_rows(const float* d, const int64_t* idx, float* dtable, int6
 int tav_patchify(const float* video, const int32_t* keep_idx, void* patches, int32_t dtype, int64_t B, int64_t F, int64_t H, int64_t W,
                  int64_t nkeep, void* stream);
 /* per row of mask [B][n] (uint8/bool; keep where mask == keep_value): write ascending indices [B][nkeep];
- * counts[B] receives the number found (host checks == nkeep when it wants to). */
+ * counts[B] receives the number found (host checks == nkeep when it wants to).  A row with fewer than nkeep kept tokens gets its
+ * last kept index (0 if none) in the remaining slots and a row with more is truncated: keep_idx is always fully written with
+ * values in [0, n), so tav_patchify / tav_gather_rows (which also clamp) never read outside their operands. */
 int tav_mask_to_index(const uint8_t* mask, int32_t keep_value, int32_t* keep_idx, int32_t* counts, int64_t B, int64_t n, int64_t nkeep,
                       void* stream);
 /* out[r][:] = table[idx[r]][:] f32 -- rows of the fixed sin-cos position table (HF videomae:80-124) for the kept tokens;
- * the result is handed to the patch-embedding GEMM as its `resid` so the add is fused. */
-int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, void* stream);
+ * the result is handed to the patch-embedding GEMM as its `resid` so the add is fused.  idx is clamped into [0, ntable). */
+int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, int64_t ntable, void* stream);
 
 /* mean over tokens: y[b][:] = mean_s x[b][s][:] (models/tav.py:478,481,488) and its backward dx[b][s][:] = dy[b][:]/S */
 int tav_mean_pool_fwd(const float* x, float* y, int64_t B, int64_t S, int64_t W, void* stream);

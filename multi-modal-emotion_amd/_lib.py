@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
 TAV_F32, TAV_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -85,7 +85,7 @@ _SIGS = {
     "tav_embed_add_bwd_parts": (C.c_int, [i64]),
     "tav_text_embed_fwd": (C.c_int, [C.POINTER(TextEmbedArgs), vp]),
     "tav_scatter_add_rows": (C.c_int, [vp, vp, vp, i64, i64, i64, vp]),
-    "tav_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "tav_gather_rows": (C.c_int, [vp, vp, vp, i64, i64, i64, vp]),
     "tav_patchify": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, i64, i64, vp]),
     "tav_mask_to_index": (C.c_int, [vp, i32, vp, vp, i64, i64, i64, vp]),
     "tav_mean_pool_fwd": (C.c_int, [vp, vp, i64, i64, i64, vp]),

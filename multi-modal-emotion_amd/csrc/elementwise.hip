@@ -203,12 +203,14 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ d, const int64
     const long r = i / W; const int c = (int)(i - r * W);
     atomicAdd(dtable + idx[r] * W + c, d[i]);
 }
-__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, float* __restrict__ out, long rows, int W4) {
+// indices are clamped into the table: a caller's bad index must read a wrong row, never fault the device
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, float* __restrict__ out, long rows, int W4, int ntable) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * W4) return;
     const long r = i / W4; const int c = (int)(i - r * W4) * 4;
     const long W = (long)W4 * 4;
-    st4(out + r * W + c, ld4(table + (long)idx[r] * W + c));
+    int t = idx[r]; t = t < 0 ? 0 : (t >= ntable ? ntable - 1 : t);
+    st4(out + r * W + c, ld4(table + (long)t * W + c));
 }
 
 // ------------------------------------------------------------------------------------------------ video patches
@@ -217,8 +219,9 @@ template <typename TD>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ video, const int32_t* __restrict__ keep_idx, TD* __restrict__ out,
                                                        int F, int Hh, int Ww, int nkeep) {
     const int j = blockIdx.x, b = blockIdx.y;
-    const int tok = keep_idx[(long)b * nkeep + j];
-    const int gw = Ww / 16, gh = Hh / 16;
+    const int gw = Ww / 16, gh = Hh / 16, ntok = (F / 2) * gh * gw;
+    int tok = keep_idx[(long)b * nkeep + j];
+    tok = tok < 0 ? 0 : (tok >= ntok ? ntok - 1 : tok);       // never index outside the clip (a short row of the mask repeats its last token)
     const int tt = tok / (gh * gw), rem = tok - tt * gh * gw, hh = rem / gw, ww = rem - hh * gw;
     TD* orow = out + ((long)b * nkeep + j) * 1536;
     for (int v = threadIdx.x; v < 384; v += 256) {           // 384 float4 = 3*2*16 rows of 16 pixels
@@ -248,6 +251,21 @@ __global__ __launch_bounds__(256) void mask_to_index_kernel(const uint8_t* __res
     for (int i = i0; i < i1; ++i)
         if (((mask[(long)b * n + i] != 0) == (keep_value != 0))) { if (pos < nkeep) keep_idx[(long)b * nkeep + pos] = i; ++pos; }
     if (t == 255 && counts) counts[b] = scan[255];
+    // a row with fewer than nkeep kept tokens: the unwritten slots repeat the row's last kept index (0 if it has none), so every
+    // consumer reads valid memory; the caller decides from counts[] whether that is an error
+    const int found = scan[255];
+    if (found < nkeep) {
+        __shared__ int last_kept;
+        if (t == 0) last_kept = 0;
+        __syncthreads();
+        if (cnt > 0 && scan[t] == found) {                       // the thread that owns the last kept element
+            int last = 0;
+            for (int i = i0; i < i1; ++i) if (((mask[(long)b * n + i] != 0) == (keep_value != 0))) last = i;
+            last_kept = last;
+        }
+        __syncthreads();
+        for (int k = found + t; k < nkeep; k += 256) keep_idx[(long)b * nkeep + k] = last_kept;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pooling / head / loss
@@ -646,10 +664,10 @@ extern "C" int tav_scatter_add_rows(const float* d, const int64_t* idx, float* d
     hipLaunchKernelGGL(scatter_add_rows_kernel, G1(rows * W), d, idx, dtable, (long)rows, (int)W);
     return tav_last_error();
 }
-extern "C" int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, void* stream) {
+extern "C" int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, int64_t ntable, void* stream) {
     if (!table || !idx || !out) return TAV_ERR_NULL;
-    if (rows <= 0 || W <= 0 || W % 4) return TAV_ERR_SHAPE;
-    hipLaunchKernelGGL(gather_rows_kernel, G1(rows * (W / 4)), table, idx, out, (long)rows, (int)(W / 4));
+    if (rows <= 0 || W <= 0 || W % 4 || ntable <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, G1(rows * (W / 4)), table, idx, out, (long)rows, (int)(W / 4), (int)ntable);
     return tav_last_error();
 }
 extern "C" int tav_patchify(const float* video, const int32_t* keep_idx, void* patches, int32_t dt, int64_t B, int64_t F, int64_t H, int64_t W, int64_t nkeep,

@@ -720,6 +720,8 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     const int nsplit = p.chunks_per_batch * (int)a->nbatch;
     if (nsplit != a->nsplit) return TAV_ERR_SHAPE;
     p.tiles_1 = (p.N1 + 127) / 128; p.tiles_2 = (p.N2 + 127) / 128;
+    const int inner = a->perm_inner > 0 ? a->perm_inner : p.N2, outer = a->perm_outer > 0 ? a->perm_outer : 1;
+    if (outer > 1 && inner * outer != p.N2) return TAV_ERR_SHAPE;       // checked before anything is launched
     dim3 grid(p.tiles_1 * p.tiles_2, nsplit), block(256);
     if (a->dtype == TAV_BF16) {
         const size_t lds = 4 * 64 * 256;
@@ -731,8 +733,6 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     int e = (int)hipGetLastError();
     if (e) return e;
     const long n_elems = (long)p.N1 * p.N2;
-    const int inner = a->perm_inner > 0 ? a->perm_inner : p.N2, outer = a->perm_outer > 0 ? a->perm_outer : 1;
-    if (outer > 1 && inner * outer != p.N2) return TAV_ERR_SHAPE;
     const long nthreads = (n_elems + 3) / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a->slabs, a->out, nsplit,
                        n_elems, p.N2, inner, outer, a->accumulate, a->scale == 0.f ? 1.f : a->scale, (const float*)a->bias_partials, a->dbias, p.N1);

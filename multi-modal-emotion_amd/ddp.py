@@ -24,6 +24,7 @@ class BucketedAllReduce:
         self.buckets = None
         self._ready = []
         self._pending = {}
+        self._streams = {}                           # bucket -> streams its gradients were written on (the branches run on their own)
         self._works = []
         self._manual = False
         self._cuda = self.params[0].is_cuda
@@ -64,15 +65,20 @@ class BucketedAllReduce:
         if left is None:
             left = self._pending[i] = set(self.buckets[i][0])
         left.discard(p)
+        if self._cuda:
+            # this hook runs under the stream guard of the parameter's AccumulateGrad node: remember every stream that wrote a
+            # gradient of this bucket (text / audio / video branches accumulate on their own streams, runtime.branch_streams)
+            self._streams.setdefault(i, set()).add(torch.cuda.current_stream())
         if not left:
             self._launch(i)
 
     def _launch(self, i):
         plist, flat = self.buckets[i]
         if self._cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
+            # the bucket's gradients were produced on several streams (buckets follow the ready order and span branches): the
+            # reducer stream waits for the tail of EVERY one of them, not only of the stream that completed the bucket
+            for st in self._streams.pop(i, set()) | {torch.cuda.current_stream()}:
+                self.side.wait_stream(st)
             ctx = torch.cuda.stream(self.side)
         else:
             import contextlib
@@ -83,7 +89,10 @@ class BucketedAllReduce:
             for p in plist:
                 n = p.numel()
                 v = flat[off:off + n].view_as(p)
-                v.copy_(p.grad)
+                if p.grad is None:
+                    v.zero_()                        # no gradient on this rank this step: contribute zeros, keep the collective sequence
+                else:
+                    v.copy_(p.grad)
                 views.append(v)
                 off += n
             buf = flat if self.reduce_dtype is None else flat.to(self.reduce_dtype)
@@ -104,11 +113,13 @@ class BucketedAllReduce:
             for i in range(len(self.buckets)):
                 self._launch(i)
         else:
-            for i, left in list(self._pending.items()):   # buckets with parameters that got no gradient this step
-                if left:
-                    pl = [p for p in self.buckets[i][0] if p.grad is not None]
-                    if len(pl) == len(self.buckets[i][0]):
-                        self._launch(i)
+            # Buckets not launched by the hooks: some parameter received no gradient on this rank this step.  Every rank must still
+            # issue the same collectives in the same order, so ALL remaining buckets are reduced, in index order, with zeros in the
+            # slots of the missing gradients (their .grad then becomes the mean over the ranks that did produce one).
+            launched = {i for _, i, _, _ in self._works}
+            for i in range(len(self.buckets)):
+                if i not in launched:
+                    self._launch(i)
         import contextlib
         for work, i, buf, views in self._works:
             plist, flat = self.buckets[i]
@@ -122,6 +133,7 @@ class BucketedAllReduce:
                 p.grad = v
         self._works = []
         self._pending = {}
+        self._streams = {}
         if self._cuda:
             torch.cuda.current_stream().wait_stream(self.side)
 

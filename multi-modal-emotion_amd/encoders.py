@@ -8,6 +8,7 @@ used ONLY as named parameter holders so that `state_dict()` matches what a refer
   VideoEncoder  <- HF VideoMAEModel                 (keys: embeddings.patch_embeddings.projection.*, encoder.layer.N.*)
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -15,6 +16,9 @@ from torch import nn
 
 from . import engine as E
 from . import ops, runtime
+
+
+_DEBUG_CHECKS = os.environ.get("TAV_DEBUG_CHECKS", "0") == "1"      # host-synchronising input checks on the sync-free paths
 
 
 def _holder(**children):
@@ -269,12 +273,23 @@ class VideoEncoder(nn.Module):
         ectx = runtime.ctx()
         _need_cuda(video, "VideoEncoder")
         B = video.shape[0]
+        host_checked = nkeep is None
         if nkeep is None:
             total = int((~bool_masked_pos).sum().item())        # host sync; pass nkeep to avoid it
             if total % B:
                 raise ValueError("visible token count not divisible by the batch size")
             nkeep = total // B
-        idx, _ = ops.mask_to_index(bool_masked_pos.contiguous(), False, nkeep)
+        if not 0 < nkeep <= bool_masked_pos.shape[1]:
+            raise ValueError(f"VideoEncoder.embed: {nkeep} kept tokens per row out of {bool_masked_pos.shape[1]}")
+        idx, counts = ops.mask_to_index(bool_masked_pos.contiguous(), False, nkeep)
+        # HF's `embeddings[~mask].reshape(B, -1, C)` mixes utterances when rows keep different numbers of tokens (the reference's
+        # collate only equalises the TOTAL, models/tav.py:211-217); here that is an error, not a silent shuffle.  The kernels are
+        # safe either way (mask_to_index pads short rows with a valid index); the check costs a host read, so it runs when the
+        # host already synchronised to count, or on request (TAV_DEBUG_CHECKS=1) when the caller passed nkeep / n_visual_true.
+        if host_checked or _DEBUG_CHECKS:
+            c = counts.cpu()
+            if not bool((c == nkeep).all()):
+                raise ValueError(f"visual mask keeps {c.tolist()} tokens per row; every row must keep the same number ({nkeep})")
         p = self.embeddings.patch_embeddings.projection
         x = E.PatchEmbedFn.apply(video, idx, p.weight, p.bias, self._pos_table, ectx)
         return x, nkeep

@@ -337,7 +337,7 @@ def scatter_add_rows(d, idx, ntable):
 def gather_rows(table, idx):
     rows, W = idx.numel(), table.shape[1]
     out = torch.empty(rows, W, dtype=torch.float32, device=table.device)
-    check(lib().tav_gather_rows(ptr(table), ptr(idx), ptr(out), rows, W, stream()), "gather_rows")
+    check(lib().tav_gather_rows(ptr(table), ptr(idx), ptr(out), rows, W, table.shape[0], stream()), "gather_rows")
     return out
 
 

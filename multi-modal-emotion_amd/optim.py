@@ -13,13 +13,30 @@ class _PtrTable:
     """Pinned host staging + device array of int64 (pointers / sizes), refreshed with an async copy."""
 
     def __init__(self, n, device):
-        self.host = torch.empty(n, dtype=torch.int64).pin_memory()
+        # two pinned staging buffers used in turn: the asynchronous H2D copy of step k may still be pending when the host prepares
+        # step k+1 (eager mode at large batch: the GPU lags the host), so a buffer is rewritten only after ITS last copy finished
+        self.host = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.done = [None, None]
+        self.turn = 0
+        self.last = None
         self.dev = torch.empty(n, dtype=torch.int64, device=device)
 
     def set(self, values):
+        if self.last == values:                      # unchanged (gradient arena, graph replay): nothing to upload
+            return self.dev
         n = len(values)
-        self.host[:n].copy_(torch.tensor(values, dtype=torch.int64))
-        self.dev[:n].copy_(self.host[:n], non_blocking=True)
+        k = self.turn
+        self.turn ^= 1
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        self.host[k][:n].copy_(torch.tensor(values, dtype=torch.int64))
+        self.dev[:n].copy_(self.host[k][:n], non_blocking=True)
+        self.done[k] = None
+        if self.dev.is_cuda and not torch.cuda.is_current_stream_capturing():     # (a captured copy replays from a table that no longer changes)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.done[k] = ev
+        self.last = list(values)
         return self.dev
 
 
@@ -47,7 +64,7 @@ class FusedAdamW:
     def _ensure(self, act):
         dev = act[0].device
         n = len(act)
-        if self._tables is None or self._tables[0].host.numel() < n:
+        if self._tables is None or self._tables[0].dev.numel() < n:
             self._tables = tuple(_PtrTable(max(n, len(self.params)), dev) for _ in range(5))
             self._scal = torch.zeros(8, dtype=torch.float32, device=dev)
             self._step_dev = torch.full((1,), int(getattr(self, "_loaded_step", 0)), dtype=torch.int32, device=dev)
