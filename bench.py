@@ -1,69 +1,90 @@
-"""Benchmark of the TAV hot path on MI355X: utterances/s of the full training step
+"""Benchmark of the TAV hot path on MI355X: utterances/s of the training step
 (PreFormer.forward -> TAVForMAE.forward(check="val") -> CE -> backward [-> gradient all-reduce] -> clip_grad_norm_ -> AdamW)
 on synthetic MELD-shaped batches (text 128 tokens, audio 16 kHz x 5 s, video 16x3x224x224, 104 fusion / 1464 encoder video tokens),
-preset B (bert-base + wav2vec2-base + videomae-base), bf16 operands / f32 accumulate, batch 8 per GPU.
+preset B (bert-base + wav2vec2-base + videomae-base), bf16 operands / f32 accumulate.
+
+The workload is BASELINE.json's headline: GLOBAL batch 32.  One GPU runs all 32 utterances; N GPUs shard them as 32/N contiguous rows
+per rank, replicated weights, one gradient mean per step over RCCL -- total work is fixed, so "scaling": "strong".
+`--batch-per-gpu B` switches to the weak variant (B utterances on every GPU).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 ...          # starts the 8 ranks itself (python -m torch.distributed.run, 127.0.0.1) before touching a GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (gemm_nt, bf16 MFMA): algorithmic FLOPs / launch time measured live with HIP events
                   on the launch stream in a separate instrumented pass (the timed region itself is not instrumented);
+                  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same
+                  command, used only while the kernel sources and the workload still match what was profiled (else null);
   cpu_baseline -- the CPU oracle (oracle/tav_oracle.py, fp32 PyTorch restatement of the reference path, kind "port") timed
                   on this box's host cores on a bounded sample (rank 0, N = 1 only).
+A failed hipGraph capture is fatal (exit code 3): an eager fallback would silently time a different launch mode.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import tav_amd  # noqa: E402,F401
-from tav_amd import config as C  # noqa: E402
-from tav_amd import ops, runtime, synthetic  # noqa: E402
-from tav_amd.models.tav import PreFormer, TAVForMAE  # noqa: E402
-from tav_amd.train_model.tav_train import TrainStep  # noqa: E402
-from tav_amd.utils.global_functions import CrossEntropyLoss  # noqa: E402
-
 MFMA_PEAK_BF16_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic forward FLOPs per utterance, BASELINE.md §2 (fwd+bwd = 3x)
 FWD_GFLOP_PER_UTT = {"B": 547.0, "A": 634.8}
+GLOBAL_BATCH = 32                      # BASELINE.json metric: "... b=32, 1/2/4/8 MI355X"
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc", "traffic_per_launch.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg, pre, model, sample_b, iters):
-    """Oracle (CPU port of the reference path) fwd + loss + bwd, utterances/s on the host cores of this box."""
-    from oracle import tav_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    (tx, au, vi), lab = synthetic.make_batch(cfg, sample_b, seed=4321)
-    batch = dict(input_ids=tx["input_ids"], text_mask=tx["attention_mask"], audio_features=au["audio_features"], audio_mask=au["attention_mask"],
-                 video_embeds=vi["visual_embeds"], visual_mask=vi["attention_mask"])
-    sd_pre = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
-    sd_model = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    times = []
-    for it in range(iters + 1):
-        t0 = time.perf_counter()
-        _, loss = O.tav_step(sd_model, sd_pre, cfg, batch, lab.long())
-        loss.backward()
-        times.append(time.perf_counter() - t0)
-        log(f"cpu baseline iter {it}: {times[-1]:.2f} s (batch {sample_b}, {cores} threads)")
-        for v in list(sd_pre.values()) + list(sd_model.values()):
-            v.grad = None
-        if it >= 1 and sum(times) > 40.0:          # bounded sample
-            break
-    iters = len(times) - 1
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": round(sample_b / t, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (PyTorch CPU) fwd+loss+bwd, same preset and input shapes, batch {sample_b}, median of {iters} after 1 warm-up"}
+def kernel_source_hash():
+    """Identity of the code the PMC traffic figure was taken on: the GEMM kernel sources (there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "common.h"):
+        with open(os.path.join(ROOT, "multi-modal-emotion_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH, help="utterances per step over ALL GPUs (strong scaling: 32/N per rank)")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="> 0: weak-scaling variant, this many utterances on every GPU")
+    ap.add_argument("--preset", default="B")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fwd+bwd only, batch 8)")
+    ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"],
+                    help="bounded: b=1, 2 warm-ups, median of 5 (~25 s); full: BASELINE.md §3, b in {1, 8} (several minutes)")
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
+    ap.add_argument("--graph", type=int, default=1, help="1: capture the step into hipGraphs and replay them; 0: eager launches (debugging)")
+    ap.add_argument("--ddp-segments", type=int, default=4, help="N > 1: backward graphs per step; bucket i is reduced on a side stream while graph i+1 runs")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` run plainly: start the N ranks as a child torchrun BEFORE this process touches a GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def host_cores():
@@ -85,27 +106,67 @@ def host_cores():
     return int(os.environ.get("TAV_CPU_THREADS", min(n, 16)))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=8)
-    ap.add_argument("--preset", default="B")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--bucket-mb", type=float, default=48.0)
-    ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
-    ap.add_argument("--graph", type=int, default=1, help="1: capture the whole step into a hipGraph and replay it (single-GPU runs); 0: eager launches")
-    args = ap.parse_args()
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
+
+def cpu_baseline(torch, synthetic, cfg, pre, model, protocol):
+    """Oracle (CPU port of the reference path) fwd + loss + bwd on the host cores of this box, BASELINE.md §3: 2 warm-ups, median of 5.
+    `bounded` times batch 1 only (about 25 s of CPU work: the default bench run must finish in minutes); `full` adds batch 8."""
+    from oracle import tav_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd_pre = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+    sd_model = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    res = {}
+    for b in ((1,) if protocol == "bounded" else (1, 8)):
+        (tx, au, vi), lab = synthetic.make_batch(cfg, b, seed=4321)
+        batch = dict(input_ids=tx["input_ids"], text_mask=tx["attention_mask"], audio_features=au["audio_features"], audio_mask=au["attention_mask"],
+                     video_embeds=vi["visual_embeds"], visual_mask=vi["attention_mask"])
+        times = []
+        for it in range(7):
+            t0 = time.perf_counter()
+            _, loss = O.tav_step(sd_model, sd_pre, cfg, batch, lab.long())
+            loss.backward()
+            times.append(time.perf_counter() - t0)
+            log(f"cpu baseline b={b} iter {it}: {times[-1]:.2f} s ({cores} threads)")
+            for v in list(sd_pre.values()) + list(sd_model.values()):
+                v.grad = None
+        res[b] = b / sorted(times[2:])[len(times[2:]) // 2]
+    out = {"value": round(res[max(res)], 4), "unit": "utterances/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "sample": f"oracle fp32 (PyTorch CPU, {cores} threads) fwd+loss+bwd on the same preset and input shapes, batch {max(res)}, "
+                     "median of 5 after 2 warm-ups (BASELINE.md §3)"}
+    if len(res) > 1:
+        out["by_batch"] = {str(b): round(v, 4) for b, v in res.items()}
+    return out
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: refusing to report a {world}-GPU figure as {args.gpus} GPUs")
+        sys.exit(2)
+
+    import torch
+    import tav_amd  # noqa: F401
+    from tav_amd import config as C
+    from tav_amd import engine, ops, runtime, synthetic
+    from tav_amd.models.tav import PreFormer, TAVForMAE
+    from tav_amd.train_model.tav_train import TrainStep
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libtavhip has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -117,8 +178,15 @@ def main():
         torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=dev)
-    if args.gpus != world:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+
+    weak = args.batch_per_gpu > 0
+    if weak:
+        b, gb = args.batch_per_gpu, args.batch_per_gpu * world
+    else:
+        gb = args.global_batch
+        if gb % world:
+            raise SystemExit(f"global batch {gb} does not divide over {world} ranks")
+        b = gb // world
 
     # every step (warm-up, capture, replay) runs on ONE non-default stream: autograd ties each parameter's AccumulateGrad node to
     # the stream of its first backward, and a hipGraph cannot be captured across the legacy default stream
@@ -126,7 +194,6 @@ def main():
     torch.cuda.set_stream(work_stream)
     cfg = C.preset(args.preset)
     runtime.set_precision(args.dtype)
-    b = args.batch_per_gpu
     torch.manual_seed(0)
     pre = PreFormer(cfg)
     model = TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg)
@@ -136,7 +203,15 @@ def main():
     log(f"[rank {rank}] models built ({sum(p.numel() for p in model.parameters()) / 1e6:.0f} M + {sum(p.numel() for p in pre.parameters()) / 1e6:.0f} M params)")
     pre.to(dev)
     model.to(dev)
-    inp, labels = synthetic.make_batch(cfg, b, seed=1234 + rank, device=dev)      # resident in HBM before timing
+    if weak:
+        inp, labels = synthetic.make_batch(cfg, b, seed=1234 + rank, device=dev)      # resident in HBM before timing
+    else:
+        # strong scaling: ONE global batch (seed 1234), rank r owns its rows [r*b, (r+1)*b) -- SURVEY.md §8(e)
+        inp_g, labels_g = synthetic.make_batch(cfg, gb, seed=1234)
+        sl = slice(rank * b, (rank + 1) * b)
+        inp = [{k: v[sl].contiguous().to(dev) for k, v in d.items()} for d in inp_g]
+        labels = labels_g[sl].contiguous().to(dev)
+        del inp_g, labels_g
     n_true = 104 if cfg["video"]["image"] == 224 else 4
     stepper = TrainStep(model, pre, CrossEntropyLoss(), lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=args.bucket_mb,
                         reduce_dtype=torch.bfloat16 if args.reduce_bf16 else None)
@@ -154,6 +229,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def capture_failed(e):
+        import traceback
+        log(f"[rank {rank}] hipGraph capture FAILED ({type(e).__name__}); refusing to time an eager fallback\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
+        torch.cuda.synchronize()
+        os._exit(3)              # every rank takes this path or hangs in the next collective: leave at once, non-zero
+
     for i in range(args.warmup):
         loss = one_step()
         torch.cuda.synchronize()
@@ -161,89 +242,106 @@ def main():
 
     # hipGraph: capture one whole step (fwd, loss, bwd, clip, AdamW, weight re-casts) and replay it -- ~3000 kernel launches per
     # step would otherwise cost the Python host about as long as the GPU needs to run them.
-    graph, eager_step = None, one_step
+    graph, eager_step, launch = None, one_step, "eager"
     if args.graph and stepper.reducer is not None and not args.no_optimizer:
-        # Data parallel: two graphs per step with the gradient all-reduce issued eagerly between them, so that no RCCL call is ever
-        # captured: G1 = forward + loss + backward + pack gradients into their buckets, then one all-reduce (mean) per bucket on the
-        # work stream, then G2 = clip_grad_norm_ + AdamW reading the reduced buckets.  The host only enqueues ~35 collectives per
-        # step (the eager hook-based path -- all-reduce overlapped with the backward on a side stream -- is host bound at ~44 ms/step).
-        g1 = g2 = static_loss = None
+        # Data parallel: the step is a chain of hipGraphs with the gradient all-reduces issued eagerly between them, so that no RCCL
+        # call is ever captured (ddp.GraphedStep): the backward is cut into --ddp-segments graphs at bucket boundaries and the
+        # all-reduce of the gradients graph i produced runs on a side stream while graph i+1 executes; the last graph is
+        # clip_grad_norm_ + AdamW on the reduced buckets.
+        from tav_amd.ddp import GraphedStep
         try:
-            from tav_amd import engine
-            torch.cuda.synchronize()
-            if world > 1:
-                torch.distributed.barrier()
+            fence()
             engine.bump_weight_epoch()
             stepper.opt.zero_grad()
-            stepper.reducer.set_manual(True, bucket_mb=256.0)
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=work_stream):
-                static_loss = stepper.forward_backward(inp, labels, check="val", epoch=0, n_visual_true=n_true)
-                stepper.reducer.pack_all()
-            with torch.cuda.graph(g2, stream=work_stream, pool=g1.pool()):
-                stepper.update()
-            captured = True
+            gstep = GraphedStep(stepper, lambda: stepper.forward_loss(inp, labels, check="val", epoch=0, n_visual_true=n_true), work_stream,
+                                segments=args.ddp_segments)
         except Exception as e:
-            import traceback
-            log(f"[rank {rank}] graph capture failed ({type(e).__name__})\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
-            captured = False
-            torch.cuda.synchronize()
-        # every rank must issue the same sequence of collectives: agree BEFORE the first replay (no collective was issued since the barrier)
-        ok = torch.tensor([1.0 if captured else 0.0], device=dev)
-        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-        if ok.item() > 0.5:
-            graph = (g1, g2)
-
-            def one_step():                                  # noqa: F811
-                g1.replay()
-                stepper.reducer.reduce_packed()
-                g2.replay()
-                return static_loss
-            for _ in range(2):
-                one_step()
-            torch.cuda.synchronize()
-            log(f"[rank {rank}] step captured into two hipGraphs around {len(stepper.reducer.buckets)} eager all-reduces")
-        else:
-            log(f"[rank {rank}] falling back to eager launches (hook-mode all-reduce) on all ranks")
-            stepper.opt.zero_grad()
-            stepper.reducer.set_manual(False)
-            graph, one_step = None, eager_step
-    elif args.graph and world == 1:
+            capture_failed(e)
+        graph, one_step = gstep, gstep.run
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        launch = gstep.describe()
+        log(f"[rank {rank}] {launch}")
+    elif args.graph:
         try:
-            from tav_amd import engine
             torch.cuda.synchronize()
             engine.bump_weight_epoch()                       # the operand casts must be part of the captured step
             stepper.opt.zero_grad()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=work_stream):
                 static_loss = one_step()
+        except Exception as e:
+            capture_failed(e)
 
-            def one_step():                                  # noqa: F811
-                graph.replay()
-                return static_loss
-            for _ in range(2):
-                one_step()
-            torch.cuda.synchronize()
-            log(f"[rank {rank}] step captured into a hipGraph")
-        except Exception as e:                               # keep the benchmark alive: fall back to eager launches
-            import traceback
-            log(f"[rank {rank}] graph capture failed ({type(e).__name__}); falling back to eager\n" + "".join(traceback.format_exc().splitlines(True)[-14:]))
-            graph, one_step = None, eager_step
-            torch.cuda.synchronize()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    host_enqueue = time.perf_counter() - t0          # host time to enqueue K steps (no sync inside the loop)
-    fence()
-    elapsed = time.perf_counter() - t0
-    log(f"[rank {rank}] host enqueue {host_enqueue / args.steps * 1e3:.2f} ms/step vs wall {elapsed / args.steps * 1e3:.2f} ms/step")
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+        def one_step():                                  # noqa: F811
+            graph.replay()
+            return static_loss
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        launch = "hipGraph replay"
+        log(f"[rank {rank}] step captured into a hipGraph")
+
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        host = time.perf_counter() - t0          # host time to enqueue K steps (no sync inside the loop)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = t.item()
+        return el, host, out
+
+    elapsed, host_enqueue, loss = timed(one_step, args.steps)
     final_loss = loss.item()
+    log(f"[rank {rank}] host enqueue {host_enqueue / args.steps * 1e3:.2f} ms/step vs wall {elapsed / args.steps * 1e3:.2f} ms/step")
     log(f"[rank {rank}] timed region: {elapsed / args.steps * 1e3:.2f} ms/step, loss {final_loss:.5f}")
+
+    # ---- secondary measurements (single GPU): the same step without clip+AdamW (the metric's "fwd+bwd"), and batch 8 (BASELINE configs[1])
+    secondary = {}
+    if world == 1 and not alone_ddp and args.graph and not args.no_secondary and not args.no_optimizer:
+        def graphed(fn):
+            stepper.opt.zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=work_stream):
+                out = fn()
+            return lambda: (g.replay(), out)[1]
+
+        def fwd_bwd_only():
+            ls = stepper.forward_backward(inp, labels, check="val", epoch=0, n_visual_true=n_true)
+            stepper.opt.zero_grad()
+            return ls
+        try:
+            torch.cuda.synchronize()
+            fb = graphed(fwd_bwd_only)
+            fb()
+            el, _, _ = timed(fb, args.steps)
+            secondary["fwd_bwd_only"] = {"utterances_per_s": round(b * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3)}
+            if b > 8:
+                inp8 = [{k: v[:8].contiguous() for k, v in d.items()} for d in inp]
+                lab8 = labels[:8].contiguous()
+
+                def step8():
+                    ls = stepper.forward_backward(inp8, lab8, check="val", epoch=0, n_visual_true=n_true)
+                    stepper.update()
+                    return ls
+                for _ in range(2):
+                    step8()                                  # shapes change: warm the workspaces before capturing
+                torch.cuda.synchronize()
+                engine.bump_weight_epoch()
+                s8 = graphed(step8)
+                s8()
+                el, _, _ = timed(s8, args.steps)
+                secondary["batch_8"] = {"utterances_per_s": round(8 * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3),
+                                        "note": "BASELINE.json configs[1]: same step at 8 utterances per GPU"}
+        except Exception as e:
+            capture_failed(e)
+        log(f"[rank {rank}] secondary: {secondary}")
 
     roof = None
     if not args.no_roofline and args.dtype == "bf16":
@@ -251,7 +349,11 @@ def main():
         # Instrumented pass: eager launches (a HIP event pair per GEMM), all branches on ONE stream so that every launch has the
         # device to itself -- the same condition rocprofv3's kernel trace measures (it serialises dispatches), which is what
         # profiles/*kernel_stats* must agree with.  In the timed region above the four branches overlap.
+        if stepper.reducer is not None:
+            stepper.reducer.set_manual(False)
+        stepper.opt.zero_grad()
         runtime.multistream[0] = False
+        eager_step()                                         # shapes may have changed (secondary batch): re-warm
         ops.profile_start("gemm_nt")
         for _ in range(2):
             eager_step()
@@ -261,25 +363,30 @@ def main():
         ach = flops / max(secs, 1e-9) / 1e12
     if rank == 0 and not args.no_roofline and args.dtype == "bf16":
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE summary of this same command (profiles/r01_pmc/traffic_per_launch.json: 2 x FETCH + WRITE, averaged
-        # over every gemm_nt launch), next to the algorithmic minimum (operands + output once) counted live
-        traffic = None
+        # FETCH_SIZE / WRITE_SIZE summary of this same command (tools/pmc_traffic.py: 2 x FETCH + WRITE averaged over every gemm_nt
+        # launch), valid only while the kernel sources and the workload are the ones that were profiled
+        traffic, traffic_src = None, "no PMC summary committed for this code/workload"
         try:
-            if not (b == 8 and args.preset == "B"):
-                raise LookupError("the committed PMC summary was taken on the default workload only")
-            with open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic_per_launch.json")) as f:
-                traffic = json.load(f)["families"]["gemm_nt_kernel"]["hbm_bytes_per_launch_corrected"]
+            with open(PMC_SUMMARY) as f:
+                rec = json.load(f)
+            same = rec.get("kernel_source_hash") == kernel_source_hash() and rec.get("per_gpu_batch") == b and rec.get("preset") == args.preset
+            if same:
+                traffic = rec["families"]["gemm_nt_kernel"]["hbm_bytes_per_launch_corrected"]
+                traffic_src = f"recorded: {os.path.relpath(PMC_SUMMARY, ROOT)} (kernel sources {rec['kernel_source_hash']}, commit {rec.get('head', '?')})"
+            else:
+                traffic_src = (f"stale: {os.path.relpath(PMC_SUMMARY, ROOT)} was taken on kernel sources {rec.get('kernel_source_hash')} / batch "
+                               f"{rec.get('per_gpu_batch')}, now {kernel_source_hash()} / {b}")
         except Exception:
             pass
         roof = {"kernel": "tav::gemm_nt_kernel<bf16,*>", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(getattr(ops.profile_stop, "algorithmic_bytes", 0.0) / max(launches, 1)), "launches_per_step": launches // 2,
                 "avg_launch_us": round(secs / launches * 1e6, 2), "serial_ms_per_step": round(secs / 2 * 1e3, 3)}
 
     cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t0 = time.time()
-        cpu_ref = cpu_baseline(cfg, pre, model, args.cpu_sample_batch, args.cpu_iters)
+        cpu_ref = cpu_baseline(torch, synthetic, cfg, pre, model, args.cpu_protocol)
         log(f"cpu baseline: {cpu_ref}  ({time.time() - t0:.1f} s)")
 
     if rank == 0:
@@ -287,20 +394,22 @@ def main():
         value = utt / elapsed
         base = args.preset.split("-")[0]
         step_flops = 3 * FWD_GFLOP_PER_UTT.get(base, 0.0) * 1e9 * b
+        what = "fwd+bwd" if args.no_optimizer else "fwd+bwd (+clip_grad_norm_+AdamW inside the timed step)"
         out = {
-            "metric": "utterances/sec fwd+bwd, TAV (BERT+Wav2Vec2+VideoMAE) b=32, 1/2/4/8 MI355X",
+            "metric": f"utterances/sec {what}, TAV (BERT+Wav2Vec2+VideoMAE) b={gb}, 1/2/4/8 MI355X",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"tav_nn.py TAV preset {args.preset} (bert-base + wav2vec2-base + videomae-base), batch {b} per GPU, text 128 tok, "
-                                   f"audio 80000 samples, video 16x3x224x224 (104 fusion / 1464 encoder tokens)",
-                       "global_batch": world * b, "per_gpu_batch": b, "parallelism": f"dp{world}",
-                       "step": "PreFormer+TAVForMAE fwd, CE, bwd" + (", grad all-reduce (RCCL)" if world > 1 else "")
-                               + ("" if args.no_optimizer else ", clip_grad_norm_, AdamW"),
-                       "weights": "random init (seeded), no checkpoints offline", "final_loss": round(final_loss, 5),
-                       "launch": ("two hipGraphs + eager RCCL all-reduce" if isinstance(graph, tuple) else "hipGraph replay") if graph is not None else "eager",
+            "config": {"workload": f"tav_nn.py TAV preset {args.preset} (bert-base + wav2vec2-base + videomae-base), global batch {gb} = {b} per GPU x {world}, "
+                                   f"text 128 tok, audio 80000 samples, video 16x3x224x224 (104 fusion / 1464 encoder tokens)",
+                       "global_batch": gb, "per_gpu_batch": b, "parallelism": f"dp{world}",
+                       "step": "PreFormer+TAVForMAE fwd (check=\"val\": head dropout off, the parity configuration), CE, bwd"
+                               + (", grad all-reduce (RCCL)" if world > 1 else "") + ("" if args.no_optimizer else ", clip_grad_norm_, AdamW"),
+                       "weights": "random init (seeded), no checkpoints offline", "final_loss": round(final_loss, 5), "launch": launch,
                        "mfma_util_whole_step": round(step_flops / (elapsed / args.steps) / (MFMA_PEAK_BF16_TFLOPS * 1e12), 4)},
         }
+        if secondary:
+            out["config"]["secondary"] = secondary
         if roof is not None:
             out["roofline"] = roof
         if cpu_ref is not None:

@@ -208,7 +208,9 @@ typedef struct tav_text_embed_args {
     float eps;
 } tav_text_embed_args;
 int tav_text_embed_fwd(const tav_text_embed_args* args, void* stream);
-/* scatter-add of row gradients into a table: dtable[idx[r]][:] += d[r][:] (f32 atomics; table zeroed by caller) */
+/* scatter-add of row gradients into a table: dtable[idx[r]][:] += d[r][:] (table zeroed by caller).  No atomics: the first row
+ * of each distinct index sums all rows carrying it in ascending row order, so the result is bitwise reproducible.
+ * W % 4 == 0, W <= 1024, rows*4 + 64*W bytes of LDS <= 150 KB (rows <= ~22 k at W = 768); indices outside [0, ntable) are skipped. */
 int tav_scatter_add_rows(const float* d, const int64_t* idx, float* dtable, int64_t rows, int64_t W, int64_t ntable, void* stream);
 
 /* VideoMAE tubelet patch gather (HF videomae/modeling_videomae.py:157-177 Conv3d k=s=(2,16,16) as a GEMM A operand):

@@ -197,11 +197,73 @@ __global__ void text_embed_sum_kernel(const int64_t* __restrict__ ids, const int
     const long W = (long)W4 * 4;
     st4(pre + r * W + c, ld4(word + ids[r] * W + c) + ld4(pos + pos_ids[r] * W + c) + ld4(type + c));
 }
-__global__ void scatter_add_rows_kernel(const float* __restrict__ d, const int64_t* __restrict__ idx, float* __restrict__ dtable, long rows, int W) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * W) return;
-    const long r = i / W; const int c = (int)(i - r * W);
-    atomicAdd(dtable + idx[r] * W + c, d[i]);
+// dtable[idx[r]][:] += d[r][:] without atomics (bitwise reproducible): one workgroup per token row r.  Every workgroup lists, in
+// ascending order, the rows that carry the same index (rows <= a few thousand: rows/1024 compares per thread); only the workgroup
+// of the FIRST such row goes on and adds their sum to the table row.  Wave w sums matches w, w+16, ... (fixed order), the 16
+// partial rows meet in LDS in wave order.  A padding token shared by a quarter of the batch costs rows/64 serial row reads.
+constexpr int SCAT_T = 1024, SCAT_MAXW = 1024;
+__global__ __launch_bounds__(SCAT_T) void scatter_add_rows_kernel(const float* __restrict__ d, const int64_t* __restrict__ idx, float* __restrict__ dtable,
+                                                                  int rows, int W, long ntable) {
+    extern __shared__ __attribute__((aligned(16))) char scat_smem[];
+    // all LDS in the dynamic region (a static __shared__ object in front would move its base off 16-B alignment)
+    int* wcount = reinterpret_cast<int*>(scat_smem);                   // [16]
+    int* wbase = wcount + 16;                                          // [16]
+    int& total = wcount[32];
+    int& dup_before = wcount[33];
+    int* match = reinterpret_cast<int*>(scat_smem + 256);              // [rows] worst case
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t id = idx[r];
+    if (t == 0) dup_before = 0;
+    __syncthreads();
+    const int per = (rows + SCAT_T - 1) / SCAT_T, i0 = t * per;
+    int i1 = i0 + per; i1 = i1 < rows ? i1 : rows;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) if (idx[i] == id) { ++cnt; if (i < r) dup_before = 1; }      // benign race: every writer stores 1
+    __syncthreads();
+    if (dup_before || id < 0 || id >= ntable) return;                  // not the first row with this index (or an index outside the table)
+    // ordered compaction of the matching rows: exclusive scan of cnt over the threads (wave scan + 16 wave totals)
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wcount[wave] = incl;
+    __syncthreads();
+    if (t == 0) { int a = 0; for (int w = 0; w < 16; ++w) { wbase[w] = a; a += wcount[w]; } total = a; }
+    __syncthreads();
+    int pos = wbase[wave] + incl - cnt;
+    for (int i = i0; i < i1; ++i) if (idx[i] == id) match[pos++] = i;
+    __syncthreads();
+    const int n = total;
+    float* part = reinterpret_cast<float*>(scat_smem + 256 + (((size_t)rows * 4 + 15) & ~(size_t)15));   // [16][W]
+    // lane owns float4 columns lane, lane+64, ... (W <= 1024: at most 4)
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int W4 = W / 4;
+    for (int m = wave; m < n; m += 16) {
+        const float* src = d + (long)match[m] * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int c = lane + 64 * k; if (c < W4) acc[k] += ld4(src + 4 * c); }
+    }
+    const int nw = n < 16 ? n : 16;                                      // waves that hold a partial sum
+    if (nw > 1) {
+        if (wave < nw) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = lane + 64 * k; if (c < W4) st4(part + (long)wave * W + 4 * c, acc[k]); }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* dst = dtable + id * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < W4) {
+                f32x4 v = acc[k];
+                for (int w = 1; w < nw; ++w) v += ld4(part + (long)w * W + 4 * c);
+                st4(dst + 4 * c, ld4(dst + 4 * c) + v);
+            }
+        }
+    }
 }
 // indices are clamped into the table: a caller's bad index must read a wrong row, never fault the device
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, float* __restrict__ out, long rows, int W4, int ntable) {
@@ -660,8 +722,10 @@ extern "C" int tav_text_embed_fwd(const tav_text_embed_args* a, void* stream) {
 }
 extern "C" int tav_scatter_add_rows(const float* d, const int64_t* idx, float* dtable, int64_t rows, int64_t W, int64_t ntable, void* stream) {
     if (!d || !idx || !dtable) return TAV_ERR_NULL;
-    if (rows <= 0 || W <= 0 || ntable <= 0) return TAV_ERR_SHAPE;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, G1(rows * W), d, idx, dtable, (long)rows, (int)W);
+    if (rows <= 0 || W <= 0 || ntable <= 0 || W % 4 || W > SCAT_MAXW) return TAV_ERR_SHAPE;
+    const size_t lds = 256 + (((size_t)rows * 4 + 15) & ~(size_t)15) + (size_t)16 * W * 4;  // header + match list + 16 partial rows
+    if (lds > 150 * 1024) return TAV_ERR_SHAPE;                                           // rows <= ~22 k tokens per call at W = 768
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)rows), dim3(SCAT_T), lds, ST, d, idx, dtable, (int)rows, (int)W, (long)ntable);
     return tav_last_error();
 }
 extern "C" int tav_gather_rows(const float* table, const int32_t* idx, float* out, int64_t rows, int64_t W, int64_t ntable, void* stream) {

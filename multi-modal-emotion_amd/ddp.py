@@ -182,3 +182,150 @@ class BucketedAllReduce:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+# ====================================================================================================================
+# Graph mode with overlap: the backward in segments.
+#
+# A captured hipGraph cannot contain the RCCL calls (kept eager on purpose) and an eager hook-driven backward is host bound, so the
+# data-parallel step is a CHAIN of graphs:   G0 = forward + loss + backward of the top segment + pack bucket 0
+#                                            Gs = backward of segment s + pack bucket s            (s = 1 .. S-1)
+#                                            Gu = clip_grad_norm_ + AdamW on the reduced buckets
+# and between two graphs the host records an event on the work stream, makes the reducer stream wait for it and issues the
+# all-reduce of the bucket that graph just packed: bucket s crosses xGMI while graph s+1 differentiates the next lower layers.
+# Segments are cut where the encoder stacks reported cut tensors (runtime.cut_point): every segment spans ALL four branches (text /
+# audio / video / fusion keep running side by side on their streams inside each graph), the lowest one holds the first layers, the
+# front-ends, the embedding tables and PreFormer and is the only one whose all-reduce is exposed.
+def _walk_leaves(root_fns, stop_fns):
+    """Leaf tensors (AccumulateGrad variables) reachable from the autograd nodes `root_fns` without entering `stop_fns`."""
+    seen, out, stack = set(), [], [f for f in root_fns if f is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen or fn in stop_fns:
+            continue
+        seen.add(fn)
+        if hasattr(fn, "variable"):
+            out.append(fn.variable)
+            continue
+        stack.extend(nf for nf, _ in fn.next_functions if nf is not None)
+    return out
+
+
+class SegmentedBackward:
+    """`loss.backward()` executed as S calls.  `cuts` = {branch: [(x, x_cut), ...] in forward order} as recorded by runtime.cut_point:
+    the forward continued from the detached leaf x_cut, so the autograd graph is in pieces.  Segment s differentiates the pieces whose
+    roots are the x of the cuts segment s-1 ended at (the loss for s = 0), feeding them the gradients that arrived at the matching
+    x_cut; a branch with fewer cuts than the others reaches its leaves in an earlier segment.  Pure autograd bookkeeping (device
+    agnostic); a parameter used by several pieces accumulates and is final after the last of them."""
+
+    def __init__(self, loss, cuts):
+        per = [list(reversed(v)) for v in cuts.values() if v]
+        self.nseg = 1 + max((len(v) for v in per), default=0)
+        self.roots = [[loss]] + [[v[s][0] for v in per if len(v) > s] for s in range(self.nseg - 1)]
+        self.root_src = [[None]] + [[v[s][1] for v in per if len(v) > s] for s in range(self.nseg - 1)]     # whose gradient feeds each root
+        self.stops = [[v[s][1] for v in per if len(v) > s] for s in range(self.nseg - 1)] + [[]]
+        cut_leaves = {id(xc) for v in per for _, xc in v}
+        last = {}
+        self.leaves = []
+        for s in range(self.nseg):
+            uniq, ids = [], set()
+            for p in _walk_leaves([t.grad_fn for t in self.roots[s]], set()):
+                if id(p) not in ids and id(p) not in cut_leaves and p.requires_grad:
+                    ids.add(id(p))
+                    uniq.append(p)
+            self.leaves.append(uniq)
+            for p in uniq:
+                last[id(p)] = s
+        # parameters whose gradient is complete once segment s has run (what bucket s may ship)
+        self.final = [[p for p in self.leaves[s] if last[id(p)] == s] for s in range(self.nseg)]
+        self._pending = {}
+
+    def run(self, s):
+        """Differentiate segment s; gradients land in p.grad (added to an existing one).  Returns the parameters that are final now.
+        torch.autograd.grad rather than .backward(): captured gradients register their producer stream with the engine's final
+        stream join, so the branch streams are handled exactly as in a whole backward, and no AccumulateGrad node (with its own
+        stream affinity) is involved."""
+        roots = self.roots[s]
+        grads = None if s == 0 else [self._pending.pop(id(xc)) for xc in self.root_src[s]]
+        stops, leaves = list(self.stops[s]), self.leaves[s]
+        out = torch.autograd.grad(roots, stops + leaves, grad_outputs=grads, allow_unused=True)
+        for xc, g in zip(stops, out[:len(stops)]):
+            self._pending[id(xc)] = g
+        for p, g in zip(leaves, out[len(stops):]):
+            if g is not None:
+                p.grad = g if p.grad is None else p.grad + g
+        return self.final[s]
+
+
+class GraphedStep:
+    """The data-parallel training step of bench.py (N > 1): S+1 hipGraphs with the bucket all-reduces issued eagerly between them on the
+    reducer stream (see the block comment above).  `forward_loss()` must run PreFormer + model + criterion on static input tensors."""
+
+    def __init__(self, stepper, forward_loss, stream, segments=4):
+        from . import runtime
+        red = stepper.reducer
+        self.red, self.stepper, self.stream = red, stepper, stream
+        red.set_manual(True)
+        self.side = red.side
+        k = max(1, int(segments))
+        fr = tuple(runtime.CUT_FRACTIONS) if k == 4 else tuple((j + 0.25) / k for j in range(k - 1)) if k > 1 else ()
+        self.graphs, self.flats = [], []
+        g0 = torch.cuda.CUDAGraph()
+        runtime.begin_cuts(fr)
+        with torch.cuda.graph(g0, stream=stream):
+            self.loss = forward_loss()
+            self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
+            self._run_and_pack(0)
+        self.graphs.append(g0)
+        for s in range(1, self.seg.nseg):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, pool=g0.pool()):
+                self._run_and_pack(s)
+            self.graphs.append(g)
+        self.gu = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool()):
+            stepper.update()
+        red.buckets = [(plist, flat) for plist, flat in self.flats]
+
+    def _run_and_pack(self, s):
+        plist = [p for p in self.seg.run(s) if p.grad is not None]
+        n = sum(p.numel() for p in plist)
+        # allocated inside the capture, i.e. from the graphs' private pool: the reference kept in self.flats pins it for good, and
+        # the reducer / RCCL streams only ever touch it between two replays
+        flat = torch.empty(n, dtype=torch.float32, device=plist[0].device)
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        with torch.no_grad():
+            torch._foreach_copy_(views, [p.grad for p in plist])
+        for p, v in zip(plist, views):
+            p.grad = v
+        self.flats.append((plist, flat))
+
+    def _reduce(self, flat):
+        red = self.red
+        if not red._active:
+            return
+        buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG if red._avg else dist.ReduceOp.SUM, group=red.pg)
+        if buf is not flat:
+            flat.copy_(buf)
+        if not red._avg:
+            flat.mul_(1.0 / red.world)
+
+    def run(self):
+        main = torch.cuda.current_stream()
+        for g, (_, flat) in zip(self.graphs, self.flats):
+            g.replay()
+            self.side.wait_stream(main)                  # bucket s is packed: ship it while the next graph runs
+            with torch.cuda.stream(self.side):
+                self._reduce(flat)
+        main.wait_stream(self.side)
+        self.gu.replay()
+        return self.loss
+
+    def describe(self):
+        sizes = ", ".join(f"{flat.numel() * 4 / 2 ** 20:.0f}" for _, flat in self.flats)
+        return (f"{len(self.graphs)} hipGraphs (forward + backward cut into {self.seg.nseg} segments) + optimizer graph; bucket s all-reduced (RCCL, eager, "
+                f"side stream) while graph s+1 runs; buckets [{sizes}] MiB")

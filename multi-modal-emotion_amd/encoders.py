@@ -91,7 +91,9 @@ class TextEncoder(nn.Module):
             key_mask = ((1.0 - attention_mask.to(torch.float32)) * torch.finfo(torch.float32).min).contiguous()
             mode = 1
         spec = E.LayerSpec(B, S, c["heads"], c["eps"], pre_ln=False, mask_mode=mode)
-        for L in self.encoder.layer:
+        n = len(self.encoder.layer)
+        for i, L in enumerate(self.encoder.layer):
+            x = runtime.cut_point("text", i, n, x)
             x, x_lp = E.encoder_layer(ectx, spec, x, x_lp, key_mask, self._layer_params(L))
         seq = x.view(B, S, -1)
         first = seq[:, 0]                                                   # HF roberta:530-536
@@ -213,7 +215,9 @@ class AudioEncoder(nn.Module):
         if not c["stable_ln"]:
             x, x_lp = E.layer_norm_f32(ectx, x, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, c["eps"])
         spec = E.LayerSpec(B, T, c["heads"], c["eps"], pre_ln=c["stable_ln"], mask_mode=0)
-        for L in self.encoder.layers:
+        n = len(self.encoder.layers)
+        for i, L in enumerate(self.encoder.layers):
+            x = runtime.cut_point("audio", i, n, x)
             x, x_lp = E.encoder_layer(ectx, spec, x, x_lp, None, self._layer_params(L))
         if c["stable_ln"]:
             x, x_lp = E.layer_norm_f32(ectx, x, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, c["eps"])
@@ -299,6 +303,8 @@ class VideoEncoder(nn.Module):
         ectx, c = runtime.ctx(), self.cfg
         x, nkeep = self.embed(video, bool_masked_pos, nkeep)
         spec = E.LayerSpec(video.shape[0], nkeep, c["heads"], c["eps"], pre_ln=True, mask_mode=0)
-        for L in self.encoder.layer:
+        n = len(self.encoder.layer)
+        for i, L in enumerate(self.encoder.layer):
+            x = runtime.cut_point("video", i, n, x)
             x, _ = E.encoder_layer(ectx, spec, x, None, None, self._layer_params(L))
         return x, nkeep

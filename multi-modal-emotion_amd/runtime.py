@@ -70,3 +70,37 @@ def mark_inputs_ready():
 def take_inputs_event():
     ev, _inputs_event[0] = _inputs_event[0], None
     return ev
+
+
+# ---- backward segments (ddp.GraphedStep): while a recorder is active every encoder stack reports the residual-stream tensor that
+# enters chosen layers; the data-parallel step cuts its backward there so that the gradients of the upper layers can travel over xGMI
+# while the lower layers are still being differentiated.
+_cut_rec = None
+CUT_FRACTIONS = (1.0 / 12.0, 1.0 / 3.0, 2.0 / 3.0)      # of a stack's depth: the lowest segment (front-ends, embeddings, first layer) stays light
+
+
+def begin_cuts(fractions=CUT_FRACTIONS):
+    global _cut_rec
+    _cut_rec = {"fractions": tuple(fractions), "pts": {}}
+
+
+def end_cuts():
+    """-> {branch: [(x, x_cut) in forward order]}: x belongs to the graph below the cut, x_cut (a detached leaf) starts the graph above."""
+    global _cut_rec
+    rec, _cut_rec = _cut_rec, None
+    return rec["pts"] if rec is not None else {}
+
+
+def cut_point(branch, i, L, x):
+    """Called by an encoder stack before its layer i (of L) with the f32 residual stream entering that layer; returns the tensor the
+    stack continues with.  Without a recorder that is x itself.  With one, at the chosen depths, it is a DETACHED leaf: the autograd
+    graph is physically cut there (the engine cannot be told to stop at an interior node -- it walks through it whenever a requested
+    leaf is also reachable underneath), and ddp.SegmentedBackward chains the pieces by handing x_cut's gradient to x."""
+    if _cut_rec is None or i == 0 or not x.requires_grad:
+        return x
+    marks = sorted({min(L - 1, max(1, int(round(f * L)))) for f in _cut_rec["fractions"]})
+    if i not in marks:
+        return x
+    xc = x.detach().requires_grad_(True)
+    _cut_rec["pts"].setdefault(branch, []).append((x, xc))
+    return xc

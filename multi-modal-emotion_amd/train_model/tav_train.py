@@ -84,8 +84,11 @@ class TrainStep:
         if torch.distributed.is_available() and torch.distributed.is_initialized() and (torch.distributed.get_world_size() > 1 or alone_ok):
             self.reducer = tav_ddp.BucketedAllReduce(self.params, bucket_mb=bucket_mb, reduce_dtype=reduce_dtype, single_rank_ok=alone_ok)
 
+    def forward_loss(self, input, label, check="train", epoch=0, n_visual_true=None):
+        return get_statistics(input, label, self.model, self.pre, self.criterion, None, check=check, epoch=epoch, n_visual_true=n_visual_true)
+
     def forward_backward(self, input, label, check="train", epoch=0, n_visual_true=None):
-        loss = get_statistics(input, label, self.model, self.pre, self.criterion, None, check=check, epoch=epoch, n_visual_true=n_visual_true)
+        loss = self.forward_loss(input, label, check, epoch, n_visual_true)
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()

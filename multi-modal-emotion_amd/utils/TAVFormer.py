@@ -86,9 +86,10 @@ class VideoMAEEncoder(nn.Module):
         spec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode)
         x = hidden_states.reshape(B * S, H)
         all_hidden = () if output_hidden_states else None
-        for layer in self.layer:
+        for i, layer in enumerate(self.layer):
             if output_hidden_states:
                 all_hidden = all_hidden + (x.view(B, S, H),)
+            x = runtime.cut_point("fusion", i, len(self.layer), x)
             x, _ = E.encoder_layer(ectx, spec, x, None, key_mask, layer.params())
         out = x.view(B, S, H)
         if output_hidden_states:

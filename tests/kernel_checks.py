@@ -289,6 +289,51 @@ def check_embed_add():
     return rs
 
 
+def check_scatter_deterministic():
+    """The embedding-table gradient at the size of a real text batch: 4096 token rows, a padding id shared by a quarter of them, ids outside
+    the table skipped; equal to index_add_ and bitwise identical from run to run (no atomics)."""
+    rows, W, ntab = 4096, 768, 1000
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, ntab, (rows,), generator=g)
+    ids[torch.rand(rows, generator=g) < 0.25] = 0
+    ids[7] = 2
+    ids = ids.to(DEV)
+    dy = _rnd(rows, W, seed=91)
+    ref = torch.zeros(ntab, W, device=DEV, dtype=torch.float64).index_add_(0, ids, dy.double()).float()
+    a = ops.scatter_add_rows(dy, ids, ntab)
+    b = ops.scatter_add_rows(dy, ids, ntab)
+    bad = ids.clone()
+    bad[5] = ntab + 3                                  # out-of-table index: skipped, never written out of bounds
+    c = ops.scatter_add_rows(dy, bad, ntab)
+    ref_c = torch.zeros(ntab, W, device=DEV, dtype=torch.float64).index_add_(0, ids[torch.arange(rows, device=DEV) != 5],
+                                                                           dy.double()[torch.arange(rows, device=DEV) != 5]).float()
+    return [_res("scatter_add_rows.large", a, ref, 2e-6), _res("scatter_add_rows.bitwise_repeat", (a != b).float().sum().reshape(1), torch.zeros(1, device=DEV), 0.0),
+            _res("scatter_add_rows.bad_index_skipped", c, ref_c, 2e-6)]
+
+
+def check_index_safety():
+    """Rows of the video mask that keep FEWER tokens than nkeep (what the reference's collate can produce at batch > 1): keep_idx is still fully
+    written with in-range indices, counts report the truth, and out-of-range indices handed to the gathers are clamped instead of faulting."""
+    B, n, nkeep = 3, 96, 10
+    mask = torch.zeros(B, n, dtype=torch.bool)
+    mask[0, torch.arange(0, 40, 4)] = True              # exactly nkeep
+    mask[1, [3, 50, 95]] = True                         # short row
+    # row 2 keeps nothing
+    idx, counts = ops.mask_to_index(mask.to(DEV), True, nkeep)
+    exp = torch.zeros(B, nkeep)
+    exp[0] = torch.arange(0, 40, 4).float()
+    exp[1] = torch.tensor([3., 50., 95.] + [95.] * 7)
+    rs = [_res("mask_to_index.padded", idx.float(), exp.to(DEV), 0.0), _res("mask_to_index.counts_short", counts.float(), torch.tensor([10., 3., 0.], device=DEV), 0.0)]
+    table = _rnd(20, 64, seed=92)
+    wild = torch.tensor([0, 19, -5, 20, 1 << 30], dtype=torch.int32, device=DEV)
+    rs.append(_res("gather_rows.clamped", ops.gather_rows(table, wild), table[torch.tensor([0, 19, 0, 19, 19], device=DEV)], 0.0))
+    video = _rnd(1, 2, 3, 32, 32, seed=93)
+    ok = ops.patchify(video, torch.tensor([[3]], dtype=torch.int32, device=DEV), torch.float32)
+    hi = ops.patchify(video, torch.tensor([[1 << 20]], dtype=torch.int32, device=DEV), torch.float32)
+    rs.append(_res("patchify.clamped", hi, ok, 0.0))
+    return rs
+
+
 def check_conv0_gn(dtype):
     B, T_in, Cc, K, s = 2, 1605, 512, 10, 5
     T_out = (T_in - K) // s + 1
@@ -401,5 +446,5 @@ def all_checks():
         out.append(lambda d=dtype: check_posconv(d))
     out.append(lambda: check_gemm_nt(torch.bfloat16, out_f32=True))
     out += [check_cast_weight, check_colsum, check_text_embed, lambda: check_text_embed(-1), check_patchify,
-            check_pool_head_ce, check_embed_add]
+            check_pool_head_ce, check_embed_add, check_scatter_deterministic, check_index_safety]
     return out

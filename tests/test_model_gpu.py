@@ -72,8 +72,28 @@ def test_fusion_encoder_golden_fp32(gpu, S, mname):
         m[..., S // 4: S // 2] = 65505.0
         m[0, ..., S // 2 - 1] = 1.0
     y = enc(x, None if mname == "none" else m.cuda())
-    (y.square().mean()).backward() if False else None
+    y.square().mean().backward()
     assert rel(y, GOLD[f"fusion_S{S}_{mname}_y"]) < 1e-4
+    # backward of the post-softmax mask (reference utils/TAVFormer.py:372-383 under autograd): input gradient and a weight-gradient corner
+    assert rel(x.grad, GOLD[f"fusion_S{S}_{mname}_dx"]) < 1e-3
+    assert rel(enc.layer[0].intermediate.dense.weight.grad[:8, :8], GOLD[f"fusion_S{S}_{mname}_dW1_l0"]) < 1e-3
+
+
+@pytest.mark.parametrize("preset", ["A", "B"])
+def test_encoder_goldens_fp32(gpu, preset):
+    """The three encoders on their own against what the HF modules the reference calls produced (closed-form weights, fp32 policy):
+    bert pooled output (models/tav.py:485), wav2vec2 last hidden state (:476), videomae mean over kept tokens (:480-481)."""
+    cfg = C.preset(preset + "-tiny")
+    runtime.set_precision("fp32")
+    model = cf.fill_module_(TAVForMAE(ARGS, cfg)).cuda()
+    batch, _ = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=16, image=32, vocab=cfg["text"]["vocab"], pad_id=cfg["text"]["pad_id"], nkeep_fusion=4)
+    with torch.no_grad():
+        _, pooled = model.bert(batch["input_ids"].cuda(), batch["text_mask"].cuda())
+        aud, _, Sa = model.wav2vec2(batch["audio_features"].cuda())
+        vid, Sv = model.videomae(batch["video_embeds"].cuda(), batch["visual_mask"].cuda())
+    assert rel(pooled, GOLD[f"{preset}_text_pooled"]) < 1e-4
+    assert rel(aud.view(2, Sa, -1), GOLD[f"{preset}_audio_last"]) < 1e-4
+    assert rel(vid.view(2, Sv, -1).mean(1), GOLD[f"{preset}_video_mean"]) < 1e-4
 
 
 @pytest.mark.parametrize("preset,policy,tol", [("B", "fp32", 1e-3), ("A", "fp32", 1e-3), ("B", "bf16", 1e-2), ("A", "bf16", 1e-2)])
@@ -396,3 +416,276 @@ def test_best_pt_resume_continues(gpu, tmp_path):
     G.load_model(model_d, pre_d, None, crit, str(tmp_path))
     steps(d, 1)
     assert max(rel(pd, pa) for (_, pa), (_, pd) in zip(model_a.named_parameters(), model_d.named_parameters())) > 2e-3
+
+
+# ---- full depth, full input size: BASELINE configs 2 and 4 -----------------------------------------------------
+_ORACLE_CACHE = {}
+
+
+def _oracle_full(preset):
+    """Oracle fwd + loss + bwd at the benchmark's sizes (text 128, audio 80000, video 16x3x224x224 with 104/1464 tokens), every encoder at its
+    full depth, batch 2: computed once per preset (a few seconds of CPU) and shared by the fp32 and bf16 runs."""
+    if preset not in _ORACLE_CACHE:
+        cfg = C.preset(preset)
+        torch.manual_seed(0)
+        pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+        synthetic.seeded_init_(pre, 1)
+        synthetic.seeded_init_(model, 2)
+        (tx, au, vi), lab = synthetic.make_batch(cfg, 2)                       # reference-style masks: {0,-65504} text, {65505,1} audio (row 0 padded)
+        batch = _as_batch(tx, au, vi)
+        sdp = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+        sdm = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+        o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, lab.long())
+        o_loss.backward()
+        grads = {("pre", k): v.grad for k, v in sdp.items() if v.requires_grad and v.grad is not None}
+        grads.update({("model", k): v.grad for k, v in sdm.items() if v.requires_grad and v.grad is not None})
+        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+        state = ({k: v.detach() for k, v in sdp.items()}, {k: v.detach() for k, v in sdm.items()})
+        _ORACLE_CACHE[preset] = (cfg, batch, lab, state, o_logits.detach(), o_loss.item(), gn, grads)
+    return _ORACLE_CACHE[preset]
+
+
+@pytest.mark.parametrize("preset,policy,tol", [("B", "fp32", 1e-3), ("B", "bf16", 1e-2), ("A", "fp32", 1e-3), ("A", "bf16", 1e-2)])
+def test_full_depth_full_size_parity(gpu, preset, policy, tol):
+    """BASELINE config 2 at FULL depth (12-layer fusion stack hard-coded at reference models/tav.py:441-442, 12/12/12 or 6/24/12 encoder layers) and
+    full input sizes, against the CPU oracle on identical seeded weights and inputs: logits, loss, clip_grad_norm_ value within the north_star
+    tolerance, every parameter gradient compared (same set of trained parameters), the fused clip+AdamW reporting the same norm."""
+    cfg, batch, lab, (sdp, sdm), o_logits, o_loss, o_gn, o_grads = _oracle_full(preset)
+    runtime.set_precision(policy)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    pre.load_state_dict(sdp)
+    model.load_state_dict(sdm)
+    pre.cuda()
+    model.cuda()
+    tav, emb, amask, logits, loss = _run_product(pre, model, batch, lab)
+    assert amask.abs().max().item() > 6e4                                      # the reference-style mask really is in play (fp16 min / 65505)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_logits, e_loss = rel(logits, o_logits), abs(loss.item() - o_loss) / abs(o_loss)
+    params = list(pre.parameters()) + list(model.parameters())
+    gn = grad_norm(params).item()
+    e_gn = abs(gn - o_gn) / o_gn
+    gmax = max(g.abs().max().item() for g in o_grads.values())
+    worst, worst_k, n_cmp = 0.0, None, 0
+    for tag, mod in (("pre", pre), ("model", model)):
+        for k, p in mod.named_parameters():
+            og = o_grads.get((tag, k))
+            assert (p.grad is None) == (og is None), f"gradient presence differs for {tag}.{k}"
+            if og is not None:
+                e = (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax)
+                n_cmp += 1
+                if e > worst:
+                    worst, worst_k = e, f"{tag}.{k}"
+    print(f"[full-depth {preset} {policy}] logits {e_logits:.2e} loss {e_loss:.2e} grad-norm {e_gn:.2e} worst tensor {worst:.2e} ({worst_k}), {n_cmp} gradients")
+    assert e_logits < tol and e_loss < tol and e_gn < tol, (e_logits, e_loss, e_gn)
+    assert worst < (5e-2 if policy == "bf16" else 1e-3), (worst, worst_k)
+    opt = FusedAdamW(params, lr=1e-6, weight_decay=1e-4)
+    n = opt.clip_and_step(1.0)                                                 # train_model/tav_train.py:61-62 on the same gradients
+    assert abs(n.item() - o_gn) / o_gn < tol
+
+
+def test_config4_text_audio_10s_full_depth(gpu):
+    """BASELINE config 4: text+audio dual classifier, 10 s audio (T = 160000 -> 499 frames: the long-sequence audio attention), batch 16, every
+    encoder at full depth (preset B), bf16 policy: logits, loss and gradient norm against the CPU oracle."""
+    from tav_amd.DoubleModels.models.text_audio import BertAudioClassifier
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset("B")
+    runtime.set_precision("bf16")
+    torch.manual_seed(0)
+    model = BertAudioClassifier(dict(output_dim=7, dropout=0.5), config=cfg)
+    synthetic.seeded_init_(model, 3)
+    (tx, au, _), lab = synthetic.make_batch(cfg, 16, s_text=128, t_audio=160000, with_video=False)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    o_logits = O.text_audio_forward(sd, cfg, tx["input_ids"], tx["attention_mask"], au["audio_features"])
+    o_loss = torch.nn.functional.cross_entropy(o_logits, lab.long())
+    o_loss.backward()
+    o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.requires_grad and v.grad is not None)).item()
+    model.cuda()
+    logits = model(tx["input_ids"], tx["attention_mask"], au["audio_features"], check="val")
+    loss = CrossEntropyLoss()(logits, lab)
+    loss.backward()
+    gn = grad_norm([p for p in model.parameters() if p.grad is not None]).item()
+    e = (rel(logits, o_logits.detach()), abs(loss.item() - o_loss.item()) / abs(o_loss.item()), abs(gn - o_gn) / o_gn)
+    print(f"[config 4, b=16, T=160000, 12+12 layers, bf16] logits {e[0]:.2e} loss {e[1]:.2e} grad-norm {e[2]:.2e}")
+    assert max(e) < 1e-2, e
+    for k, p in model.named_parameters():
+        assert (p.grad is None) == (sd[k].grad is None), k
+
+
+def test_backward_is_bitwise_deterministic(gpu):
+    """run the same fwd+bwd twice (branches on their own streams) and compare every gradient bit for bit -- no kernel on the path
+    accumulates with atomics (the embedding-table gradients are segment sums, the weight gradients fixed-order slab sums)."""
+    cfg = C.preset("B")
+    for k in ("text", "audio", "video", "fusion"):
+        cfg[k]["layers"] = 2
+    runtime.set_precision("bf16")
+    torch.manual_seed(0)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    pre.cuda()
+    model.cuda()
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 4, device="cuda")
+    batch = _as_batch(tx, au, vi)
+    runs = []
+    for _ in range(2):
+        for p in list(pre.parameters()) + list(model.parameters()):
+            p.grad = None
+        _, _, _, logits, loss = _run_product(pre, model, batch, lab)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), {k: p.grad.clone() for k, p in list(model.named_parameters()) + list(pre.named_parameters()) if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 100
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_unequal_visual_rows_raise_not_fault(gpu):
+    """A visual mask whose rows keep different numbers of tokens (what the reference's collate can emit at batch > 1, models/tav.py:206-217):
+    a Python error when the host counts, and no device fault when the caller vouches for the count (n_visual_true) but is wrong."""
+    cfg = C.preset("B-tiny")
+    runtime.set_precision("bf16")
+    pre, model = PreFormer(cfg).cuda(), TAVForMAE(ARGS, cfg).cuda()
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")
+    vi["attention_mask"][1, :] = False
+    vi["attention_mask"][1, :2] = True                                          # row 1: 2 True instead of 4 (the total, 6, still divides by 2)
+    batch = _as_batch(tx, au, vi)
+    with pytest.raises(ValueError, match="same number"):
+        _run_product(pre, model, batch, lab)
+    tav, emb, amask = pre(input_ids=batch["input_ids"], audio_features=batch["audio_features"], video_embeds=batch["video_embeds"], text_mask=batch["text_mask"],
+                          audio_mask=batch["audio_mask"], visual_mask=batch["visual_mask"], device="cuda", train=False, n_visual_true=4)
+    logits = model(batch["input_ids"], batch["text_mask"], batch["audio_features"], batch["video_embeds"], batch["visual_mask"], tav, emb, amask,
+                   batch_size=2, check="val", n_visual_true=4)
+    torch.cuda.synchronize()                                                   # would surface a memory fault
+    assert torch.isfinite(logits).all()
+
+
+def test_collate_device_feeds_captured_step(gpu):
+    """collate_batch_device builds the batch ON the GPU (padding, audio length mask, equal-count video token mask) and its
+    output drives PreFormer + TAVForMAE + loss + backward captured into ONE hipGraph; replaying the graph on a second collated batch (copied into
+    the captured input buffers) reproduces the eager result on that batch."""
+    from tav_amd.models.tav import collate_batch_device
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset("B-tiny")
+    runtime.set_precision("bf16")
+    torch.manual_seed(0)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    pre.cuda()
+    model.cuda()
+    crit = CrossEntropyLoss()
+
+    def items(seed, lens):
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for L in lens:
+            ids = torch.randint(3, cfg["text"]["vocab"], (16,), generator=g)
+            out.append(([{"input_ids": ids, "attention_mask": torch.ones(16)}, torch.randn(L, generator=g) * 0.1, torch.randn(16, 3, 32, 32, generator=g)],
+                        float(torch.randint(0, 7, (1,), generator=g))))
+        return out
+
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        inp, lab = collate_batch_device(items(1, [8000, 6400]), "train", device="cuda", n_visual_true=4, generator=gen)
+        assert inp[1]["audio_features"].is_cuda and inp[2]["attention_mask"].sum(1).tolist() == [4, 4]
+        assert inp[1]["attention_mask"].sum(1).tolist() == [8000.0, 6400.0]
+
+        def step():
+            loss = __import__("tav_amd.train_model.tav_train", fromlist=["get_statistics"]).get_statistics(inp, lab, model, pre, crit, None, check="val", epoch=0, n_visual_true=4)
+            loss.backward()
+            return loss
+
+        for _ in range(2):
+            for p in list(pre.parameters()) + list(model.parameters()):
+                p.grad = None
+            step()
+        torch.cuda.synchronize()
+        for p in list(pre.parameters()) + list(model.parameters()):
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            static_loss = step()
+        inp2, lab2 = collate_batch_device(items(2, [7000, 8000]), "train", device="cuda", n_visual_true=4, generator=gen)
+        for d, d2 in zip(inp, inp2):
+            for k in d:
+                d[k].copy_(d2[k])
+        lab.copy_(lab2)
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = static_loss.item()
+        g_replayed = model.linear1.weight.grad.clone()
+        for p in list(pre.parameters()) + list(model.parameters()):
+            p.grad = None
+        eager = step()
+        torch.cuda.synchronize()
+    assert abs(replayed - eager.item()) <= 1e-6 * abs(eager.item())
+    assert torch.equal(g_replayed, model.linear1.weight.grad)
+
+
+def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
+    """bench.py's data-parallel step (ddp.GraphedStep: forward + backward cut into segments, one hipGraph each, the bucket all-reduces issued
+    eagerly on the reducer stream in between, optimizer graph last) on the real RCCL backend with ONE rank: after three steps the weights equal
+    those of the plain eager step (forward_backward + update), and the loss sequence matches."""
+    import torch.distributed as dist
+    from tav_amd import engine
+    from tav_amd.ddp import GraphedStep
+    from tav_amd.train_model.tav_train import TrainStep
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset("B")
+    for k in ("text", "audio", "video", "fusion"):
+        cfg[k]["layers"] = 4
+    cfg["video"]["image"] = 32
+    runtime.set_precision("bf16")
+
+    def build(ddp):
+        torch.manual_seed(0)
+        pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+        synthetic.seeded_init_(pre, 1)
+        synthetic.seeded_init_(model, 2)
+        pre.cuda()
+        model.cuda()
+        monkeypatch.setenv("TAV_DDP_SINGLE_RANK", "1" if ddp else "0")
+        return pre, model, TrainStep(model, pre, CrossEntropyLoss(), lr=1e-3, weight_decay=1e-2, clip=1.0)
+
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            inp, lab = synthetic.make_batch(cfg, 2, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")
+            pre_a, model_a, plain = build(False)
+            losses_a = []
+            for _ in range(4):
+                losses_a.append(plain.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4).item())
+                plain.update()
+            pre_b, model_b, st = build(True)
+            assert st.reducer is not None
+            # step 1 eagerly (hook-mode reducer), as bench.py's warm-up does: the optimizer state must exist before the capture
+            losses_b = [st.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4).item()]
+            st.update()
+            torch.cuda.synchronize()
+            engine.bump_weight_epoch()
+            st.opt.zero_grad()
+            g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4)
+            assert g.seg.nseg == 4 and len(g.graphs) == 4
+            assert sum(len(pl) for pl, _ in g.flats) == len([p for p in st.params if p.grad is not None])
+            for _ in range(3):
+                # (the capture itself executed nothing: the first replay is step 2)
+                losses_b.append(g.run().item())
+            torch.cuda.synchronize()
+            st.reducer.remove()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    print("graphed ddp:", g.describe(), losses_a, losses_b)
+    for la, lb in zip(losses_a, losses_b):
+        assert abs(la - lb) <= 1e-6 * abs(la), (losses_a, losses_b)
+    worst = 0.0
+    for (k, pa), (_, pb) in zip(list(model_a.named_parameters()) + list(pre_a.named_parameters()), list(model_b.named_parameters()) + list(pre_b.named_parameters())):
+        worst = max(worst, rel(pb, pa))
+    assert worst < 1e-6, worst
