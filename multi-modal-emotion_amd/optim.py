@@ -71,6 +71,9 @@ class FusedAdamW:
             self._lr_pin = torch.empty(1, dtype=torch.float32).pin_memory()
         for p in act:
             if p not in self.state:
+                if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                    # zeros allocated inside a capture would be re-zeroed by every replay: the moments must exist before
+                    raise RuntimeError("FusedAdamW: run one eager optimizer step before capturing the step into a hipGraph")
                 self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
 
     def clip_and_step(self, max_norm=None):
