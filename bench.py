@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
     ap.add_argument("--graph", type=int, default=1, help="1: capture the step into hipGraphs and replay them; 0: eager launches (debugging)")
+    ap.add_argument("--profile-serial", action="store_true",
+                    help="profiling mode: eager launches, every branch on ONE stream, so that a rocprofv3 --kernel-trace --stats of this command sees each "
+                         "kernel alone on the device (the condition of the roofline pass); the utterances/s of such a run is not the headline")
     ap.add_argument("--ddp-segments", type=int, default=4, help="N > 1: backward graphs per step; bucket i is reduced on a side stream while graph i+1 runs")
     return ap.parse_args()
 
@@ -149,6 +152,8 @@ def cpu_baseline(torch, synthetic, cfg, pre, model, protocol):
 
 def main():
     args = parse_args()
+    if args.profile_serial:
+        args.graph, args.no_secondary, args.no_cpu_baseline = 0, True, True
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         self_launch(args)
@@ -194,6 +199,8 @@ def main():
     torch.cuda.set_stream(work_stream)
     cfg = C.preset(args.preset)
     runtime.set_precision(args.dtype)
+    if args.profile_serial:
+        runtime.multistream[0] = False
     torch.manual_seed(0)
     pre = PreFormer(cfg)
     model = TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg)
@@ -242,7 +249,7 @@ def main():
 
     # hipGraph: capture one whole step (fwd, loss, bwd, clip, AdamW, weight re-casts) and replay it -- ~3000 kernel launches per
     # step would otherwise cost the Python host about as long as the GPU needs to run them.
-    graph, eager_step, launch = None, one_step, "eager"
+    graph, eager_step, launch = None, one_step, "eager launches, one stream (--profile-serial)" if args.profile_serial else "eager"
     if args.graph and stepper.reducer is not None and not args.no_optimizer:
         # Data parallel: the step is a chain of hipGraphs with the gradient all-reduces issued eagerly between them, so that no RCCL
         # call is ever captured (ddp.GraphedStep): the backward is cut into --ddp-segments graphs at bucket boundaries and the
@@ -359,7 +366,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         flops, secs, launches = ops.profile_stop()
-        runtime.multistream[0] = True
+        runtime.multistream[0] = not args.profile_serial
         ach = flops / max(secs, 1e-9) / 1e12
     if rank == 0 and not args.no_roofline and args.dtype == "bf16":
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc

@@ -47,6 +47,7 @@ class BertAudioClassifier(nn.Module):
             ev = torch.cuda.Event()
             ev.record(main)
             s_aud = runtime.branch_streams(3)[0]
+            runtime.share_with(s_aud, audio_features)
             with torch.cuda.stream(s_aud):
                 s_aud.wait_event(ev)
                 aud, Sa = audio_branch()

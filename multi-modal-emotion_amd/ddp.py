@@ -270,20 +270,23 @@ class GraphedStep:
         k = max(1, int(segments))
         fr = tuple(runtime.CUT_FRACTIONS) if k == 4 else tuple((j + 0.25) / k for j in range(k - 1)) if k > 1 else ()
         self.graphs, self.flats = [], []
+        # capture_error_mode "thread_local": the process group's watchdog thread polls its work events (hipEventQuery) at any time;
+        # under the default global mode such a call from ANOTHER thread invalidates the capture (hipErrorStreamCaptureUnsupported)
+        mode = dict(capture_error_mode="thread_local")
         g0 = torch.cuda.CUDAGraph()
         runtime.begin_cuts(fr)
-        with torch.cuda.graph(g0, stream=stream):
+        with torch.cuda.graph(g0, stream=stream, **mode):
             self.loss = forward_loss()
             self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
             self._run_and_pack(0)
         self.graphs.append(g0)
         for s in range(1, self.seg.nseg):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, pool=g0.pool()):
+            with torch.cuda.graph(g, stream=stream, pool=g0.pool(), **mode):
                 self._run_and_pack(s)
             self.graphs.append(g)
         self.gu = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool()):
+        with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool(), **mode):
             stepper.update()
         red.buckets = [(plist, flat) for plist, flat in self.flats]
 

@@ -103,6 +103,8 @@ class PreFormer(nn.Module):
             ev = torch.cuda.Event()
             ev.record(main)
             s_a, s_v = runtime.front_streams(2)
+            runtime.share_with(s_a, audio_features, audio_mask)
+            runtime.share_with(s_v, video_embeds, visual_mask)
             with torch.cuda.stream(s_a):
                 s_a.wait_event(ev)
                 x_audio = audio_frontend()
@@ -203,6 +205,9 @@ class TAVForMAE(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(main)
             s_aud, s_vid, s_txt = runtime.branch_streams(3)
+            runtime.share_with(s_aud, audio_features)
+            runtime.share_with(s_vid, video_embeds, visual_mask)
+            runtime.share_with(s_txt, input_ids, text_attention_mask)
             with torch.cuda.stream(s_vid):
                 s_vid.wait_event(ev)
                 vid, Sv = self.videomae(video_embeds, visual_mask, nkeep)                # :480

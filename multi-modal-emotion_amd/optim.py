@@ -27,8 +27,8 @@ class _PtrTable:
         n = len(values)
         k = self.turn
         self.turn ^= 1
-        if self.done[k] is not None:
-            self.done[k].synchronize()
+        if self.done[k] is not None and not (self.dev.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.done[k].synchronize()               # (never under capture: an event wait on the host would invalidate it)
         self.host[k][:n].copy_(torch.tensor(values, dtype=torch.int64))
         self.dev[:n].copy_(self.host[k][:n], non_blocking=True)
         self.done[k] = None

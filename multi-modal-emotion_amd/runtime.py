@@ -57,6 +57,15 @@ def front_streams(n=2):
     return _front[dev]
 
 
+def share_with(stream, *tensors):
+    """Tensors allocated under the caller's stream (e.g. a batch just shipped to the device) that a branch stream will read, also in its
+    backward: tell the caching allocator, or the block is handed out again on the caller's stream the moment the last reference dies on
+    the HOST -- while the branch's kernels that read it may not have run yet (found as a wrong conv0 weight gradient at full size)."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
+
+
 def mark_inputs_ready():
     """Record 'the batch is resident' on the current stream (called at the start of PreFormer.forward): the encoder branches of
     TAVForMAE wait for this event only, not for PreFormer's own kernels."""

@@ -466,16 +466,20 @@ def test_full_depth_full_size_parity(gpu, preset, policy, tol):
     gn = grad_norm(params).item()
     e_gn = abs(gn - o_gn) / o_gn
     gmax = max(g.abs().max().item() for g in o_grads.values())
-    worst, worst_k, n_cmp = 0.0, None, 0
+    worst, worst_k, n_cmp, table = 0.0, None, 0, []
     for tag, mod in (("pre", pre), ("model", model)):
         for k, p in mod.named_parameters():
             og = o_grads.get((tag, k))
             assert (p.grad is None) == (og is None), f"gradient presence differs for {tag}.{k}"
             if og is not None:
-                e = (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax)
+                ae = (p.grad.detach().cpu() - og).abs().max().item()
+                e = ae / (og.abs().max().item() + 1e-3 * gmax)
+                table.append((e, f"{tag}.{k}", og.abs().max().item(), ae))
                 n_cmp += 1
                 if e > worst:
                     worst, worst_k = e, f"{tag}.{k}"
+    for e, k, m, ae in sorted(table, reverse=True)[:6]:
+        print(f"    {k:80s} err {e:.2e}  |ref|max {m:.3e}  abs err {ae:.3e}  (gmax {gmax:.3e})")
     print(f"[full-depth {preset} {policy}] logits {e_logits:.2e} loss {e_loss:.2e} grad-norm {e_gn:.2e} worst tensor {worst:.2e} ({worst_k}), {n_cmp} gradients")
     assert e_logits < tol and e_loss < tol and e_gn < tol, (e_logits, e_loss, e_gn)
     assert worst < (5e-2 if policy == "bf16" else 1e-3), (worst, worst_k)
@@ -672,7 +676,7 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
             engine.bump_weight_epoch()
             st.opt.zero_grad()
             g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4)
-            assert g.seg.nseg == 4 and len(g.graphs) == 4
+            assert g.seg.nseg == 3 and len(g.graphs) == 3          # 4-layer stacks are cut before layers 1 and 3
             assert sum(len(pl) for pl, _ in g.flats) == len([p for p in st.params if p.grad is not None])
             for _ in range(3):
                 # (the capture itself executed nothing: the first replay is step 2)

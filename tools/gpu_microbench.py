@@ -28,7 +28,7 @@ def rnd(*s, dtype=torch.bfloat16):
     return torch.randn(*s, device=dev).to(dtype)
 
 
-B = int(os.environ.get("TAV_B", "8"))
+B = int(os.environ.get("TAV_B", "32"))
 for dtype in (torch.bfloat16, torch.float32):
     print(f"== {dtype}  (batch {B})")
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
