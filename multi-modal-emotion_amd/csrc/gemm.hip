@@ -212,10 +212,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const int n = n0 + 4 * ch;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (n < p.N && p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
+    constexpr int NIT = EP_ROWS / RPI;                      // rows per thread and pass (<= 16)
+    static_assert(EP_ROWS % RPI == 0 && NIT <= 16, "epilogue rows per thread");
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
         const int row_lo = pass * EP_ROWS;
         if (pass) __syncthreads();                          // the previous pass has been stored
+        // Side inputs of this pass (f32 residual, pre-activation for gelu', or C itself when accumulating) are requested BEFORE the
+        // accumulators are staged: their HBM/L2 latency then runs under the LDS writes and the barrier instead of in front of every
+        // store (the fragment registers of the main loop are dead by now).  One flavour per launch; the rare combinations fall back
+        // to loading inside the store loop.
+        constexpr int PD = TNW == 8 ? 8 : NIT;              // requests in flight per thread (the 256 x 256 tile has 128 accumulator registers live)
+        f32x4 side[PD];                                     // (gelu_in: two packed words in .x/.y)
+        const bool pre_r = R != nullptr, pre_g = !pre_r && Gin != nullptr && sizeof(T) == 2, pre_c = !pre_r && !pre_g && p.accumulate;
+        auto side_load = [&](int it) -> f32x4 {
+            const int m = m0 + row_lo + rr + it * RPI;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N && m < p.M) {
+                if (pre_r) v = ld4(R + (long)m * p.ld_resid + n);
+                else if (pre_c) { if constexpr (sizeof(TO) == 4) v = ld4(reinterpret_cast<const float*>(C) + (long)m * p.ldc + n); }
+                else if (pre_g) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(Gin) + ((long)m * p.ld_gelu + n) * 2);
+                    v[0] = __uint_as_float(w.x);
+                    v[1] = __uint_as_float(w.y);
+                }
+            }
+            return v;
+        };
+        auto side_loads = [&]() {
+            if (!(pre_r || pre_c || pre_g)) return;
+#pragma unroll
+            for (int it = 0; it < PD; ++it) side[it] = side_load(it);
+        };
+        constexpr bool EARLY = (TNW == 4);                  // the 256 x 256 tile has no registers to spare while its accumulators are live
+        if constexpr (EARLY) side_loads();
         if (wm * 16 * TM >= row_lo && wm * 16 * TM < row_lo + EP_ROWS) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -227,23 +257,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 }
             }
         }
+        if constexpr (!EARLY) side_loads();                 // staged accumulators are dead: all 16 requests fly across the barrier
         __syncthreads();
         if (n < p.N) {
-#pragma unroll 4
-            for (int r = rr; r < EP_ROWS; r += RPI) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = rr + it * RPI;
                 const int m = m0 + row_lo + r;
-                if (m >= p.M) break;
-                f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
-                v = v * p.alpha + bv;
-                if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
-                if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
-                if (Gin) {
-                    f32x4 u = ld4(Gin + (long)m * p.ld_gelu + n);
-                    v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
+                const f32x4 sv = side[it % PD];
+                if constexpr (PD < NIT) { if (it + PD < NIT && (pre_r || pre_c || pre_g)) side[it % PD] = side_load(it + PD); }
+                if (m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
+                    v = v * p.alpha + bv;
+                    if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
+                    if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
+                    if (Gin) {
+                        f32x4 u;
+                        if (pre_g) {
+                            const uint32_t w0 = __float_as_uint(sv[0]), w1 = __float_as_uint(sv[1]);
+                            u = f32x4{bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu), bf16_bits_to_f32(w1 >> 16)};
+                        }
+                        else u = ld4(Gin + (long)m * p.ld_gelu + n);
+                        v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
+                    }
+                    if (pre_r) v += sv;
+                    else if (R) v += ld4(R + (long)m * p.ld_resid + n);
+                    if (p.accumulate) {
+                        if (pre_c && sizeof(TO) == 4) v += sv;
+                        else v += ld4(C + (long)m * p.ldc + n);
+                    }
+                    st4(C + (long)m * p.ldc + n, v);
                 }
-                if (R) v += ld4(R + (long)m * p.ld_resid + n);
-                if (p.accumulate) v += ld4(C + (long)m * p.ldc + n);
-                st4(C + (long)m * p.ldc + n, v);
             }
         }
     }
@@ -535,7 +579,9 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 using namespace tav;
 
 // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in) {
+// `epi`: what the epilogue moves and computes besides the plain store -- bit 0: f32 residual (or accumulate) read, bit 1: f32 output,
+// bit 2: GELU (+ second output) or gelu'(side input).
+static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in, int epi) {
     const int tiles_n = (N + 127) / 128;
     int tm = 4;
     double best = 1e30;
@@ -545,18 +591,20 @@ static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in) {
         if (cost < best - 1e-9) { best = cost; tm = c; }
     }
     // 256x256 (8 waves, one workgroup per CU) against the 128-wide winner, in microseconds: rounds x (K-tiles x time per K-tile + prologue
-    // and epilogue), constants fitted to the tile sweep of tools/gpu_ab.py (they reproduce its timings within ~5 %).  The big tile
-    // moves half the bytes per FLOP through LDS (1.30 PFLOP/s at 4096^3 against 1.15) but its grid is 4x coarser.
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("TAV_NT_BIG"); big = e ? atoi(e) : 1; }
-    if (big && bf16_in && M >= 256 && N >= 256) {
-        static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.62, 0.80, 0.94}, fix[5] = {0, 0, 3.0, 3.5, 4.0};
+    // and epilogue), constants fitted to tools/gpu_ab.py `tiles` and `layer` at batch 32 (they reproduce its timings within ~5 %).  The big
+    // tile stages half the bytes per FLOP (1.35 PFLOP/s at 4096^3 against 1.15) but nothing on its CU computes while it runs its epilogue,
+    // whereas two 128-wide workgroups per CU overlap one's epilogue with the other's main loop: memory-heavy epilogues (f32 residual in,
+    // f32 out) favour the small tile, plain bf16 outputs the big one.
+    if (bf16_in && M >= 256 && N >= 256) {
+        static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.56, 0.72, 0.85}, fix[5] = {0, 0, 4.2, 4.9, 5.6};
         const double nk = (double)K / 64.0;
         const long t_small = (long)((M + 32 * tm - 1) / (32 * tm)) * tiles_n * nz;
         const long t_big = (long)((M + 255) / 256) * ((N + 255) / 256) * nz;
-        const double us_small = (double)((long)((t_small + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm]);
-        const double us_big = (double)((t_big + 255) / 256) * (nk * 1.65 + 8.0);
-        if (us_big < 0.93 * us_small) tm = 16;
+        const double e_small = ((epi & 1) ? 8.0 : 0.0) + ((epi & 2) ? 5.0 : 0.0) + ((epi & 4) ? 4.5 : 0.0);
+        const double e_big = ((epi & 1) ? 18.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 10.0 : 0.0);
+        const double us_small = (double)((long)((t_small + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm] + e_small * tm / 4.0);
+        const double us_big = (double)((t_big + 255) / 256) * (nk * 1.48 + 9.4 + e_big);
+        if (us_big < 0.98 * us_small) tm = 16;
     }
     return tm;
 }
@@ -588,7 +636,8 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     int tm = a->tile_m_hint & 31;                            // 2/3/4: 64/96/128 x 128 tiles (4 waves); 8: 256 x 128, 16: 256 x 256 (8 waves)
     int nst = (a->tile_m_hint >> 5) & 7;                     // tuning: LDS ring depth 2..4 (0 = let the library choose)
     if (a->in_dtype != TAV_BF16 && (tm == 8 || tm == 16)) tm = 4;
-    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K, nzb * p.nzg, a->in_dtype == TAV_BF16);
+    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K, nzb * p.nzg, a->in_dtype == TAV_BF16,
+                                                                        ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0));
     const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + bn - 1) / bn;
@@ -629,11 +678,7 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     return (int)hipGetLastError();
 }
 
-static double split_penalty() {
-    static double v = -1.0;
-    if (v < 0.0) { const char* e = getenv("TAV_TN_SPLIT_PENALTY"); v = e ? atof(e) : 0.06; }   // tuned with the four branch streams running concurrently
-    return v;
-}
+static double split_penalty() { return 0.06; }   // per extra token split (slab traffic), tuned with the four branch streams running concurrently
 
 extern "C" int tav_gemm_tn_splits(int64_t n1, int64_t n2, int64_t rows_per_batch, int64_t nbatch, int32_t* chunk_rows, int32_t* nsplit) {
     if (!chunk_rows || !nsplit || n1 <= 0 || n2 <= 0 || rows_per_batch <= 0 || nbatch <= 0) return TAV_ERR_SHAPE;

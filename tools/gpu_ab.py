@@ -57,6 +57,29 @@ if "gemm" in what:
         bias = torch.randn(N, device=dev)
         lo, med = timeit(lambda: ops.gemm_nt(a, b, bias=bias))
         print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N * K / lo / 1e6:7.1f} TF")
+if "layer" in what:       # the eight NT GEMMs of ONE video-encoder layer (forward + dgrad) with their real epilogues, and their sum
+    M, H, F = B * 1464, 768, 3072
+    x_lp, w_qkv, w_o, w_1, w_2 = rnd(M, H), rnd(3 * H, H), rnd(H, H), rnd(F, H), rnd(H, F)
+    w_qkv_t, w_o_t, w_1_t, w_2_t = rnd(H, 3 * H), rnd(H, H), rnd(H, F), rnd(F, H)
+    b3, b1, bf = torch.randn(3 * H, device=dev), torch.randn(H, device=dev), torch.randn(F, device=dev)
+    res = torch.randn(M, H, device=dev)
+    h_lp, u_lp, dqkv = rnd(M, F), rnd(M, F), rnd(M, 3 * H)
+    tmh = int(os.environ.get("TAV_TM", "0"))
+    cases = [("qkv      bias            -> bf16", lambda: ops.gemm_nt(x_lp, w_qkv, bias=b3, tile_m=tmh), 2 * M * 3 * H * H),
+             ("out-proj bias+resid      -> f32 ", lambda: ops.gemm_nt(x_lp, w_o, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * H),
+             ("ffn1     bias+gelu+pre   -> bf16", lambda: ops.gemm_nt(x_lp, w_1, bias=bf, act=1, want_pre=True, tile_m=tmh), 2 * M * F * H),
+             ("ffn2     bias+resid      -> f32 ", lambda: ops.gemm_nt(h_lp, w_2, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
+             ("d ffn2   * gelu'(u)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, gelu_in=u_lp, tile_m=tmh), 2 * M * F * H),
+             ("d ffn1                   -> f32 ", lambda: ops.gemm_nt(h_lp, w_1_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
+             ("d out-proj               -> bf16", lambda: ops.gemm_nt(x_lp, w_o_t, tile_m=tmh), 2 * M * H * H),
+             ("d qkv                    -> f32 ", lambda: ops.gemm_nt(dqkv, w_qkv_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * 3 * H)]
+    tot_t = tot_f = 0.0
+    for name, fn, fl in cases:
+        lo, med = timeit(fn, iters=20, reps=5)
+        tot_t += lo
+        tot_f += fl
+        print(f"[{tag}] layer-NT {name}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+    print(f"[{tag}] layer-NT total (b={B}, tile hint {tmh}): {tot_t:8.1f} us  {tot_f / tot_t / 1e6:7.1f} TF")
 if "tn" in what:
     for (name, M, N1, N2) in [("video dWqkv", B * 1464, 2304, 768), ("video dWo", B * 1464, 768, 768), ("video dW1", B * 1464, 3072, 768),
                               ("video dW2", B * 1464, 768, 3072), ("text dW1", B * 128, 3072, 768)]:
