@@ -36,8 +36,11 @@ const char* tav_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GEMM, "NT": C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][n][k] )
- *   epi(v): v += bias[n]; if C_pre: C_pre = v; if act==1: v = gelu_erf(v); if gelu_in: v *= gelu'(gelu_in[m][n]);
+ *   epi(v): v += bias[n]; if C_pre: C_pre = (act & 2) ? gelu'(v) : v; if act & 1: v = gelu_erf(v);
+ *           if gelu_in: v *= (act & 4) ? gelu_in[m][n] : gelu'(gelu_in[m][n]);
  *           if resid: v += resid[m][n] (f32); if accumulate: v += C[m][n]; C = v.
+ *   (act 3 in the forward FFN1 + act 4 in its dgrad: the derivative of the GELU is computed once, next to the GELU itself -- they share
+ *    the exponential -- and the backward epilogue is a plain multiply.)
  * Replaces nn.functional.linear / nn.Linear on the path (utils/TAVFormer.py:348-350,401-403,419,432; HF linears),
  * their input-gradients (with B = W^T), nn.Conv1d of the wav2vec2 feature encoder (A rows overlap: lda = stride*C_in,
  * K = k*C_in, z = batch) and the grouped positional conv (z = batch x group).
@@ -54,7 +57,8 @@ typedef struct tav_gemm_nt_args {
     int32_t nzb, nzg;       /* 0 is read as 1 */
     int64_t a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg;
     int32_t in_dtype, out_dtype;
-    int32_t act;            /* 0 none, 1 exact-erf GELU */
+    int32_t act;            /* bit 0: exact-erf GELU; bit 1: C_pre receives gelu'(pre-activation) instead of the pre-activation;
+                               bit 2: gelu_in already holds that derivative (multiply, do not differentiate) */
     int32_t accumulate;
     float alpha;
     int32_t tile_m_hint;    /* 0 = let the library choose; bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands); bits 5-7: LDS ring depth 2-4 (tuning / tests) */

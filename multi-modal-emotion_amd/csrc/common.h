@@ -198,4 +198,19 @@ template <typename T> TAV_DEV float gelu_grad_t(float x);
 template <> TAV_DEV float gelu_grad_t<float>(float x) { return gelu_grad_f(x); }
 template <> TAV_DEV float gelu_grad_t<bf16>(float x) { float c, e; gelu_parts_fast(x, c, e); return c + x * e * 0.39894228040143267794f; }
 
+// gelu(x) and gelu'(x) together (they share the exponential / the erf): the FFN1 epilogue stores the derivative for the backward
+// pass instead of the pre-activation, so the dgrad epilogue multiplies by it without any transcendental
+template <typename T> TAV_DEV void gelu_both_t(float x, float& y, float& dy);
+template <> TAV_DEV void gelu_both_t<float>(float x, float& y, float& dy) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    y = x * cdf;
+    dy = cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+template <> TAV_DEV void gelu_both_t<bf16>(float x, float& y, float& dy) {
+    float c, e;
+    gelu_parts_fast(x, c, e);
+    y = x * c;
+    dy = fmaf(x * 0.39894228040143267794f, e, c);
+}
+
 }  // namespace tav

@@ -269,8 +269,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 if (m < p.M) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
                     v = v * p.alpha + bv;
-                    if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, v);
-                    if (p.act == 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
+                    if (Cpre && !(p.act & 2)) st4(Cpre + (long)m * p.ld_pre + n, v);
+                    if ((p.act & 3) == 3) {                     // GELU out, gelu' to C_pre
+                        f32x4 d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<T>(v[e], y, dy); v[e] = y; d[e] = dy; }
+                        if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, d);
+                    } else if (p.act & 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
                     if (Gin) {
                         f32x4 u;
                         if (pre_g) {
@@ -278,7 +283,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                             u = f32x4{bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu), bf16_bits_to_f32(w1 >> 16)};
                         }
                         else u = ld4(Gin + (long)m * p.ld_gelu + n);
-                        v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]);
+                        if (p.act & 4) v *= u;                  // the side input already is gelu'(pre-activation)
+                        else { v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]); }
                     }
                     if (pre_r) v += sv;
                     else if (R) v += ld4(R + (long)m * p.ld_resid + n);

@@ -235,7 +235,7 @@ class EncoderLayerFn(torch.autograd.Function):
             _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
         else:
             x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
-        h, u = ops.gemm_nt(c, w1_n, bias=b1, act=1, want_pre=True)
+        h, u = ops.gemm_nt(c, w1_n, bias=b1, act=3, want_pre=True)          # u = gelu'(W1 c + b1): what the backward multiplies by
         y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=x1, out_dtype=torch.float32)
         if spec.pre_ln:
             x2, x2_lp = y2, None
@@ -271,7 +271,7 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
         # FFN
-        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
+        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u, act=4)
         if spec.pre_ln:
             dc = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
@@ -777,7 +777,7 @@ class TransformerBlockFn(torch.autograd.Function):
         if p_drop > 0:
             d, m2 = ops.dropout_fwd(n1, p_drop, seed, 1 << 40)
             f_in = _to_lp(pol, d)
-        h, u = ops.gemm_nt(f_in, w1_n, bias=b1, act=1, want_pre=True)
+        h, u = ops.gemm_nt(f_in, w1_n, bias=b1, act=3, want_pre=True)
         y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=n1, out_dtype=torch.float32)
         if p_drop > 0:
             y2, m3 = ops.dropout_fwd(y2, p_drop, seed, 2 << 40)
@@ -803,7 +803,7 @@ class TransformerBlockFn(torch.autograd.Function):
             dy2 = ops.dropout_bwd(dy2, m3, p_drop)
         dy2_lp = _to_lp(pol, dy2)
         dW2, dB2 = ops.gemm_tn(dy2_lp, h, want_bias=True)
-        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u)
+        du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u, act=4)
         dW1, dB1 = ops.gemm_tn(du, f_in, want_bias=True)
         df = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)               # grad wrt dropout_f(n1)
         if m2 is not None:

@@ -66,6 +66,24 @@ def check_gemm_nt_gelu_bwd(dtype, M=200, N=384, K=256):
     return [_res(f"gemm_nt.gelu_bwd[{dtype}]", out, ref, 1e-2 if dtype == torch.bfloat16 else 2e-5)]
 
 
+def check_gemm_nt_gelu_derivative_pair(dtype, M=300, N=384, K=256, tile_m=0):
+    """act 3 (forward FFN1: GELU out + gelu' stored in C_pre) and act 4 (dgrad: multiply by the stored derivative) against autograd."""
+    a = _rnd(M, K, dtype=dtype, seed=11)
+    b = _rnd(N, K, dtype=dtype, scale=0.1, seed=12)
+    bi = _rnd(N, seed=13)
+    h, gp = ops.gemm_nt(a, b, bias=bi, act=3, want_pre=True, tile_m=tile_m)
+    pre = (a.float() @ b.float().t() + bi).requires_grad_(True)
+    y = F.gelu(pre)
+    (gr,) = torch.autograd.grad(y.sum(), pre)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5
+    rs = [_res(f"gemm_nt.act3.gelu[{dtype},tm{tile_m}]", h, y.detach(), tol), _res(f"gemm_nt.act3.gelu'[{dtype},tm{tile_m}]", gp, gr, tol)]
+    dy = _rnd(M, K, dtype=dtype, seed=14)
+    w_t = _rnd(N, K, dtype=dtype, scale=0.1, seed=15)
+    du = ops.gemm_nt(dy, w_t, gelu_in=gp, act=4, tile_m=tile_m)
+    rs.append(_res(f"gemm_nt.act4[{dtype},tm{tile_m}]", du, (dy.float() @ w_t.float().t()) * gp.float(), tol))
+    return rs
+
+
 def check_gemm_tn(dtype, M=1000, N1=256, N2=384, nbatch=1):
     a = _rnd(nbatch * M, N1, dtype=dtype, seed=8)
     b = _rnd(nbatch * M, N2, dtype=dtype, seed=9)
@@ -422,6 +440,9 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=16))
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
+        out.append(lambda d=dtype: check_gemm_nt_gelu_derivative_pair(d))
+        if dtype == torch.bfloat16:
+            out.append(lambda d=dtype: check_gemm_nt_gelu_derivative_pair(d, M=700, N=768, K=128, tile_m=16))
         out.append(lambda d=dtype: check_gemm_tn(d))
         out.append(lambda d=dtype: check_gemm_tn(d, M=249, N1=768, N2=512, nbatch=3))
         out.append(lambda d=dtype: check_gemm_tn_grouped(d))
