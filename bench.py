@@ -33,8 +33,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_BF16_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic forward FLOPs per utterance, BASELINE.md §2 (fwd+bwd = 3x)
-FWD_GFLOP_PER_UTT = {"B": 547.0, "A": 634.8}
+MFMA_PEAK_FP8_TFLOPS = 5000.0         # dense fp8 (block-scaled MFMA), same guide
+
+
+def fwd_gflop_per_utt(cfg, s_text=128, t_audio=80000):
+    """Algorithmic forward FLOPs per utterance, SURVEY.md §8(d) / BASELINE.md §2: per transformer layer 8 S H^2 + 4 S H F + 4 S^2 H; the wav2vec2
+    conv stack, feature projection and positional conv; the tubelet patch embedding over all tokens (as the reference computes it); fwd+bwd = 3x.
+    Reproduces the table there (preset B 547.0, preset A with 70 text tokens 634.8) and extends it to config 5."""
+    def stack(L, S, H, F):
+        return L * (8 * S * H * H + 4 * S * H * F + 4 * S * S * H)
+    a, v, t, f = cfg["audio"], cfg["video"], cfg["text"], cfg["fusion"]
+    lens, T, cin, conv = [], t_audio, 1, 0
+    for cd, k, st in zip(a["conv_dim"], a["conv_kernel"], a["conv_stride"]):
+        T = (T - k) // st + 1
+        conv += 2 * T * cin * k * cd
+        cin = cd
+    sa, ha = T, a["hidden"]
+    front = conv + 2 * sa * a["conv_dim"][-1] * ha + 2 * sa * ha * (ha // a["pos_groups"]) * a["pos_k"]
+    ntok = (v["image"] // v["patch"]) ** 2 * (v["frames"] // v["tubelet"])
+    n_fus = ntok // 15                                     # 1568 -> 104, 3136 -> 209
+    patch = 2 * ntok * v["hidden"] * 3 * v["tubelet"] * v["patch"] ** 2
+    bridge = lambda n: (2 * n * v["hidden"] * 768 if v["hidden"] != 768 else 0)      # noqa: E731
+    pre = front + 2 * sa * ha * 768 + patch + bridge(n_fus)
+    s_f = s_text + sa + n_fus
+    model = (stack(t["layers"], s_text, t["hidden"], t["inter"]) + front + stack(a["layers"], sa, ha, a["inter"]) + 2 * sa * ha * 768
+             + patch + stack(v["layers"], ntok - n_fus, v["hidden"], v["inter"]) + bridge(ntok - n_fus) + stack(f["layers"], s_f, f["hidden"], f["inter"]))
+    return (pre + model) / 1e9, n_fus
+
 GLOBAL_BATCH = 32                      # BASELINE.json metric: "... b=32, 1/2/4/8 MI355X"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc", "traffic_per_launch.json")
 
@@ -60,7 +85,8 @@ def parse_args():
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH, help="utterances per step over ALL GPUs (strong scaling: 32/N per rank)")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="> 0: weak-scaling variant, this many utterances on every GPU")
     ap.add_argument("--preset", default="B")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8: e4m3 operands (per-tensor scales) in the linear layers of every transformer block, the rest as bf16 (BASELINE config 5)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -88,6 +114,12 @@ def self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}")
     sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def describe(cfg):
+    t, a, v = cfg["text"], cfg["audio"], cfg["video"]
+    return (f"{t['kind']} {t['layers']} L + wav2vec2 {a['layers']} L / {a['hidden']} + videomae {v['layers']} L / {v['hidden']} on {v['frames']} frames "
+            f"+ fusion {cfg['fusion']['layers']} L")
 
 
 def host_cores():
@@ -219,7 +251,7 @@ def main():
         inp = [{k: v[sl].contiguous().to(dev) for k, v in d.items()} for d in inp_g]
         labels = labels_g[sl].contiguous().to(dev)
         del inp_g, labels_g
-    n_true = 104 if cfg["video"]["image"] == 224 else 4
+    fwd_gf, n_true = fwd_gflop_per_utt(cfg)
     stepper = TrainStep(model, pre, CrossEntropyLoss(), lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=args.bucket_mb,
                         reduce_dtype=torch.bfloat16 if args.reduce_bf16 else None)
 
@@ -351,7 +383,7 @@ def main():
         log(f"[rank {rank}] secondary: {secondary}")
 
     roof = None
-    if not args.no_roofline and args.dtype == "bf16":
+    if not args.no_roofline and args.dtype != "fp32":
         # (every rank runs it: in hook mode these steps contain the gradient all-reduces, which must be matched by all ranks)
         # Instrumented pass: eager launches (a HIP event pair per GEMM), all branches on ONE stream so that every launch has the
         # device to itself -- the same condition rocprofv3's kernel trace measures (it serialises dispatches), which is what
@@ -365,10 +397,11 @@ def main():
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
-        flops, secs, launches = ops.profile_stop()
+        flops, secs, launches = ops.profile_stop("fp8" if args.dtype == "fp8" else "bf16")
         runtime.multistream[0] = not args.profile_serial
         ach = flops / max(secs, 1e-9) / 1e12
-    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
+        peak = MFMA_PEAK_FP8_TFLOPS if args.dtype == "fp8" else MFMA_PEAK_BF16_TFLOPS
+    if rank == 0 and not args.no_roofline and args.dtype != "fp32":
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE summary of this same command (tools/pmc_traffic.py: 2 x FETCH + WRITE averaged over every gemm_nt
         # launch), valid only while the kernel sources and the workload are the ones that were profiled
@@ -385,8 +418,8 @@ def main():
                                f"{rec.get('per_gpu_batch')}, now {kernel_source_hash()} / {b}")
         except Exception:
             pass
-        roof = {"kernel": "tav::gemm_nt_kernel<bf16,*>", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        roof = {"kernel": f"tav::gemm_nt_kernel<{args.dtype},*>", "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(getattr(ops.profile_stop, "algorithmic_bytes", 0.0) / max(launches, 1)), "launches_per_step": launches // 2,
                 "avg_launch_us": round(secs / launches * 1e6, 2), "serial_ms_per_step": round(secs / 2 * 1e3, 3)}
 
@@ -399,16 +432,16 @@ def main():
     if rank == 0:
         utt = world * b * args.steps
         value = utt / elapsed
-        base = args.preset.split("-")[0]
-        step_flops = 3 * FWD_GFLOP_PER_UTT.get(base, 0.0) * 1e9 * b
+        step_flops = 3 * fwd_gf * 1e9 * b
         what = "fwd+bwd" if args.no_optimizer else "fwd+bwd (+clip_grad_norm_+AdamW inside the timed step)"
         out = {
             "metric": f"utterances/sec {what}, TAV (BERT+Wav2Vec2+VideoMAE) b={gb}, 1/2/4/8 MI355X",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"tav_nn.py TAV preset {args.preset} (bert-base + wav2vec2-base + videomae-base), global batch {gb} = {b} per GPU x {world}, "
-                                   f"text 128 tok, audio 80000 samples, video 16x3x224x224 (104 fusion / 1464 encoder tokens)",
+            "config": {"workload": f"tav_nn.py TAV preset {args.preset} ({describe(cfg)}), global batch {gb} = {b} per GPU x {world}, text 128 tok, audio 80000 "
+                                   f"samples, video {cfg['video']['frames']}x3x{cfg['video']['image']}x{cfg['video']['image']} ({n_true} fusion / "
+                                   f"{(cfg['video']['image'] // 16) ** 2 * (cfg['video']['frames'] // 2) - n_true} encoder tokens), {fwd_gf:.1f} GFLOP forward per utterance",
                        "global_batch": gb, "per_gpu_batch": b, "parallelism": f"dp{world}",
                        "step": "PreFormer+TAVForMAE fwd (check=\"val\": head dropout off, the parity configuration), CE, bwd"
                                + (", grad all-reduce (RCCL)" if world > 1 else "") + ("" if args.no_optimizer else ", clip_grad_norm_, AdamW"),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-enum { TAV_F32 = 0, TAV_BF16 = 1 };
+enum { TAV_F32 = 0, TAV_BF16 = 1, TAV_FP8 = 2 /* OCP e4m3, GEMM operands of tav_gemm_nt only */ };
 enum {
     TAV_ERR_NULL = -1,  /* required pointer missing           */
     TAV_ERR_SHAPE = -2, /* size not supported by the kernel   */
@@ -45,7 +45,12 @@ const char* tav_error_string(int code);
  * their input-gradients (with B = W^T), nn.Conv1d of the wav2vec2 feature encoder (A rows overlap: lda = stride*C_in,
  * K = k*C_in, z = batch) and the grouped positional conv (z = batch x group).
  * z = zb * nzg + zg; A/C offsets use both zb and zg strides, B/bias are offset per zg (and zb if b_zb != 0).
- * Constraints: K*sizeof(in) % 128 == 0, N % 4 == 0, strides multiples of 16 bytes.  in f32 => out f32. */
+ * Constraints: K*sizeof(in) % 128 == 0, N % 4 == 0, strides multiples of 16 bytes.  in f32 => out f32.
+ * in_dtype TAV_FP8 (BASELINE config 5): A and B are e4m3 bytes quantised with per-tensor scales (tav_fp8_amax / tav_fp8_quantize); the
+ * products run on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: twice the bf16 FLOP rate), accumulate in
+ * f32, and the epilogue multiplies by *a_dequant * *b_dequant before the bias; gelu_in is bf16, outputs bf16 or f32.  The weight
+ * gradient of a linear layer is the same call on the TRANSPOSED quantised copies (K = tokens, split over z = nzb with f32 slabs summed
+ * by tav_splitk_reduce). */
 typedef struct tav_gemm_nt_args {
     const void* A; const void* B; void* C;
     void* C_pre;            /* optional, dtype/layout of C                               */
@@ -61,6 +66,8 @@ typedef struct tav_gemm_nt_args {
                                bit 2: gelu_in already holds that derivative (multiply, do not differentiate) */
     int32_t accumulate;
     float alpha;
+    const float* a_dequant; /* in_dtype == TAV_FP8: device scalars (amax/448 of each operand, tav_fp8_amax) multiplied into alpha; NULL = 1 */
+    const float* b_dequant;
     int32_t tile_m_hint;    /* 0 = let the library choose; bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands); bits 5-7: LDS ring depth 2-4 (tuning / tests) */
 } tav_gemm_nt_args;
 int tav_gemm_nt(const tav_gemm_nt_args* args, void* stream);
@@ -101,6 +108,17 @@ typedef struct tav_gemm_tn_problem {
     int64_t N1, N2, lda, ldb;
 } tav_gemm_tn_problem;
 int tav_gemm_tn_grouped(const tav_gemm_tn_problem* problems, int32_t nproblems, int64_t rows, int32_t dtype, void* stream);
+
+/* FP8 operand preparation (sync free: the scale never leaves the device).  scales[0] = 448/amax (quantisation), scales[1] = amax/448
+ * (the dequantisation factor for tav_gemm_nt), scales[2] = amax.  partials: tav_fp8_amax_partials(rows, cols) floats. */
+int tav_fp8_amax_partials(int64_t rows, int64_t cols);
+int tav_fp8_amax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, float* partials, float* scales, void* stream);
+/* q[r][c] = e4m3(x[r][c] * scales[0]) (row stride ld_q bytes) and/or the transposed copy qt[c][r] (row stride ld_qt >= rows_pad), whose
+ * token axis is padded with zeros up to rows_pad -- the K axis of the weight-gradient GEMM.  x is f32 or bf16, cols % 4 == 0. */
+int tav_fp8_quantize(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, const float* scales, void* q, int64_t ld_q, void* qt,
+                     int64_t ld_qt, int64_t rows_pad, void* stream);
+/* out[i] (+)= sum_s slabs[s][i], s < nsplit, i < n_elems (n_elems % 4 == 0): fixed order, bitwise reproducible */
+int tav_splitk_reduce(const float* slabs, float* out, int32_t nsplit, int64_t n_elems, int32_t accumulate, void* stream);
 
 /* Column sums (bias gradients): out[n] (+)= sum_m x[m][n]; partials = workspace nparts*N f32. */
 int tav_colsum(const void* x, int32_t dtype, int64_t M, int64_t N, int64_t ld, float* partials, int32_t nparts, float* out,

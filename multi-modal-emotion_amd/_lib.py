@@ -12,8 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
-TAV_F32, TAV_BF16 = 0, 1
-ABI_VERSION = 2
+TAV_F32, TAV_BF16, TAV_FP8 = 0, 1, 2
+ABI_VERSION = 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -24,7 +24,8 @@ class GemmNTArgs(C.Structure):
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("ld_pre", i64), ("ld_gelu_in", i64), ("ld_resid", i64),
                 ("nzb", i32), ("nzg", i32),
                 ("a_zb", i64), ("a_zg", i64), ("b_zb", i64), ("b_zg", i64), ("c_zb", i64), ("c_zg", i64), ("bias_zg", i64),
-                ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("alpha", f32), ("tile_m_hint", i32)]
+                ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("alpha", f32),
+                ("a_dequant", vp), ("b_dequant", vp), ("tile_m_hint", i32)]
 
 
 class GemmTNArgs(C.Structure):
@@ -68,6 +69,10 @@ _SIGS = {
     "tav_gemm_tn": (C.c_int, [C.POINTER(GemmTNArgs), vp]),
     "tav_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTNProblem), i32, i64, i32, vp]),
     "tav_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp, i32, vp]),
+    "tav_fp8_amax_partials": (C.c_int, [i64, i64]),
+    "tav_fp8_amax": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp]),
+    "tav_fp8_quantize": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, i64, vp]),
+    "tav_splitk_reduce": (C.c_int, [vp, vp, i32, i64, i32, vp]),
     "tav_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_ln_fwd": (C.c_int, [C.POINTER(LnArgs), vp]),
@@ -161,7 +166,9 @@ def dt(t_or_dtype):
         return TAV_F32
     if d == torch.bfloat16:
         return TAV_BF16
-    raise TypeError(f"libtavhip supports float32 and bfloat16 tensors, got {d}")
+    if d == torch.float8_e4m3fn:
+        return TAV_FP8
+    raise TypeError(f"libtavhip supports float32, bfloat16 and (GEMM operands) float8_e4m3fn tensors, got {d}")
 
 
 def stream():

@@ -24,6 +24,12 @@ _PRESETS = {
         video=_VIDEO, fusion=_FUSION, output_dim=7),
 }
 
+# BASELINE config 5: preset B with videomae-large (24 L, 1024 / 16 heads / 4096) on 32 frames (3136 tubelet tokens, 209 fed to the fusion stack).
+# The reference hard-codes 768-wide video features (models/tav.py:446 LayerNorm(768), :372 concat with 768-wide text/audio tokens), so a
+# 1024-wide video encoder needs the same bridge the reference already uses for its 1024-wide audio encoder (:363 wav_2_768, :457/478
+# wav_2_768_2): a Linear(1024, 768) after the patch embedding in PreFormer ("vid_2_768") and after the encoder in TAVForMAE ("vid_2_768_2").
+_PRESETS["B5"] = dict(_PRESETS["B"], video=dict(layers=24, hidden=1024, heads=16, inter=4096, frames=32, image=224, patch=16, tubelet=2, eps=1e-12))
+
 _current = ["A"]
 
 

@@ -1,0 +1,138 @@
+// FP8 (OCP e4m3) operand preparation for the fp8 GEMM path (BASELINE config 5: videomae-large, 32 frames).
+//
+// Per-tensor "current" scaling, sync free: amax -> scale = 448 / amax lives in a device scalar that the quantiser and the GEMM epilogue
+// read, so nothing returns to the host and the whole step stays graph-capturable.
+//   tav_fp8_amax      x [rows, cols] (f32 / bf16, row stride ld) -> scales[0] = 448/amax (quantisation scale), scales[1] = amax/448
+//                     (dequantisation factor the GEMM multiplies back), scales[2] = amax
+//   tav_fp8_quantize  q[r][c] = e4m3(x[r][c] * scales[0])  and, optionally, the TRANSPOSED copy qt[c][r] with the token axis padded with
+//                     zeros to rows_pad: the weight-gradient dW = dY^T X is then the same NT GEMM (K = tokens) as every other product,
+//                     so one fp8 kernel serves forward, dgrad and wgrad
+//   tav_splitk_reduce out = sum_s slabs[s]   (the token axis of a wgrad is split over workgroups; fixed order, no atomics)
+// v_cvt_pk_fp8_f32 rounds to nearest even and saturates to +-448 (OCP e4m3fn on gfx950; MI300's fnuz encoding is not used anywhere).
+#include "common.h"
+#include "tavhip_internal.h"
+
+namespace tav {
+
+constexpr float FP8_MAX = 448.0f;
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long rows, int cols4, long ld) {
+    // grid-stride over 16-B (f32) / 8-B (bf16) groups of 4 elements; one partial per workgroup
+    __shared__ float red[4];
+    const long n4 = rows * cols4;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / cols4; const int c = (int)(i - r * cols4) * 4;
+        const f32x4 v = ld4(x + r * ld + c);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void fp8_amax_final_kernel(const float* __restrict__ part, int n, float* __restrict__ scales) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const bool ok = m > 0.f && m < 3.0e38f;              // all-zero (or non-finite) tensors quantise with scale 1
+        scales[0] = ok ? FP8_MAX / m : 1.f;
+        scales[1] = ok ? m / FP8_MAX : 1.f;
+        scales[2] = m;
+    }
+}
+
+TAV_DEV uint32_t pack4_fp8(f32x4 v) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    return (uint32_t)w;
+}
+
+// 64 x 64 tiles: row-major copy with 4-byte stores (64-B row segments) and, through LDS, the transposed copy.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ x, const float* __restrict__ scales, uint8_t* __restrict__ q,
+                                                           uint8_t* __restrict__ qt, int rows, int cols, long ld, long ld_q, long ld_qt, int rows_pad) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64][68];
+    const float sc = scales[0];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int cq = threadIdx.x & 15, rh = threadIdx.x >> 4;           // 16 column groups of 4, 16 row slots
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rh + 16 * i, c = c0 + 4 * cq;
+        uint32_t w = 0;
+        if (r < rows && c < cols) {
+            const f32x4 v = ld4(x + (long)r * ld + c) * sc;
+            w = pack4_fp8(v);
+            if (q) *reinterpret_cast<uint32_t*>(q + (long)r * ld_q + c) = w;
+        }
+        *reinterpret_cast<uint32_t*>(&tile[rh + 16 * i][4 * cq]) = w;   // rows past the end stay zero: they are the K padding of qt
+    }
+    if (!qt) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + rh + 16 * i, r = r0 + 4 * cq;
+        if (c < cols && r < rows_pad) {
+            const int cl = rh + 16 * i;
+            const uint32_t w = (uint32_t)tile[4 * cq][cl] | ((uint32_t)tile[4 * cq + 1][cl] << 8) | ((uint32_t)tile[4 * cq + 2][cl] << 16) |
+                               ((uint32_t)tile[4 * cq + 3][cl] << 24);
+            *reinterpret_cast<uint32_t*>(qt + (long)c * ld_qt + r) = w;
+        }
+    }
+}
+
+__global__ void fp8_splitk_reduce_kernel(const float* __restrict__ S, float* __restrict__ out, int nsplit, long n4, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) v += ld4(S + ((long)s * n4 + i) * 4);
+    if (accumulate) v += ld4(out + i * 4);
+    st4(out + i * 4, v);
+}
+
+}  // namespace tav
+using namespace tav;
+#define ST ((hipStream_t)stream)
+
+extern "C" int tav_fp8_amax_partials(int64_t rows, int64_t cols) {
+    const long n4 = rows * (cols / 4);
+    long nb = (n4 + 256 * 8 - 1) / (256 * 8);                 // >= 8 groups per thread
+    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+}
+extern "C" int tav_fp8_amax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, float* partials, float* scales, void* stream) {
+    if (!x || !partials || !scales) return TAV_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4) return TAV_ERR_SHAPE;
+    if (ld % 4) return TAV_ERR_ALIGN;
+    const int nb = tav_fp8_amax_partials(rows, cols);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_amax_partial_kernel<bf16>), dim3(nb), dim3(256), 0, ST, (const bf16*)x, partials, (long)rows, (int)(cols / 4), (long)ld);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_amax_partial_kernel<float>), dim3(nb), dim3(256), 0, ST, (const float*)x, partials, (long)rows, (int)(cols / 4), (long)ld);
+    else return TAV_ERR_DTYPE;
+    hipLaunchKernelGGL(fp8_amax_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)partials, nb, scales);
+    return tav_last_error();
+}
+extern "C" int tav_fp8_quantize(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, const float* scales, void* q, int64_t ld_q,
+                                void* qt, int64_t ld_qt, int64_t rows_pad, void* stream) {
+    if (!x || !scales || (!q && !qt)) return TAV_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4) return TAV_ERR_SHAPE;
+    if (ld % 4 || (q && ld_q % 4) || (qt && (ld_qt % 4 || rows_pad % 4 || rows_pad < rows || ld_qt < rows_pad))) return TAV_ERR_ALIGN;
+    const long rp = qt ? rows_pad : rows;
+    dim3 grid(tav_cdiv(cols, 64), tav_cdiv(rp, 64));
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16>), grid, dim3(256), 0, ST, (const bf16*)x, scales, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float>), grid, dim3(256), 0, ST, (const float*)x, scales, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+extern "C" int tav_splitk_reduce(const float* slabs, float* out, int32_t nsplit, int64_t n_elems, int32_t accumulate, void* stream) {
+    if (!slabs || !out) return TAV_ERR_NULL;
+    if (nsplit <= 0 || n_elems <= 0 || n_elems % 4) return TAV_ERR_SHAPE;
+    const long n4 = n_elems / 4;
+    hipLaunchKernelGGL(fp8_splitk_reduce_kernel, dim3(tav_cdiv(n4, 256)), dim3(256), 0, ST, slabs, out, nsplit, n4, accumulate);
+    return tav_last_error();
+}

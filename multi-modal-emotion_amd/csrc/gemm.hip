@@ -29,6 +29,7 @@ struct GemmNT {
     int act, accumulate;
     float alpha;
     int tiles_m, tiles_n;
+    const float* sa; const float* sb;                   // fp8 operands: device scalars multiplied into alpha (the dequantisation factors)
 };
 
 TAV_DEV int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -60,6 +61,8 @@ TAV_DEV int xcd_remap(int id, int total) {
 template <typename T, typename TO, int TM, int NST, int NW, int TNW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
+    constexpr bool F8 = std::is_same<T, fp8>::value;      // e4m3 operands: 128 k-values per 128-byte K-tile, one block-scaled MFMA per 16x16 tile
+    using TS = typename std::conditional<F8, bf16, T>::type;   // dtype of the epilogue's side input / activation flavour
     constexpr int BM = 8 * TM * NW, BN = 32 * TNW;        // TNW = 16-column MFMA tiles per wave along N (4: BN = 128, 8: BN = 256)
     constexpr int PB = BN / 8 / NW;                       // DMA pieces of the B image per wave (the A image: TM per wave)
     constexpr int NP = TM + PB;                           // DMA pieces per wave per K-tile
@@ -161,7 +164,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
+            for (int tm = 0; tm < TM; ++tm) {
+                if constexpr (F8) mma16_fp8(fb0[tn], fb1[tn], fa0[tm], fa1[tm], acc[tn][tm]);
+                else TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
+            }
             if constexpr (decltype(prefetch)::value) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -174,10 +180,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (!F8) {
 #pragma unroll
-        for (int tn = 0; tn < TNW; ++tn)
+            for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
+                for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
+        }
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const long coff = zb * p.c_zb + zg * p.c_zg;
     TO* C = reinterpret_cast<TO*>(p.C) + coff;
     TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
-    const T* Gin = p.gelu_in ? reinterpret_cast<const T*>(p.gelu_in) + coff : nullptr;
+    const TS* Gin = p.gelu_in ? reinterpret_cast<const TS*>(p.gelu_in) + coff : nullptr;
+    const float alpha = p.alpha * (p.sa ? *p.sa : 1.f) * (p.sb ? *p.sb : 1.f);
     const float* R = p.resid ? p.resid + coff : nullptr;
     const int ch = tid % CPR, rr = tid / CPR;              // this thread's 16-B column chunk (fixed) and row within an iteration
     constexpr int RPI = 64 * NW / CPR;                      // rows per iteration of the store loop
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
         // to loading inside the store loop.
         constexpr int PD = TNW == 8 ? 8 : NIT;              // requests in flight per thread (the 256 x 256 tile has 128 accumulator registers live)
         f32x4 side[PD];                                     // (gelu_in: two packed words in .x/.y)
-        const bool pre_r = R != nullptr, pre_g = !pre_r && Gin != nullptr && sizeof(T) == 2, pre_c = !pre_r && !pre_g && p.accumulate;
+        const bool pre_r = R != nullptr, pre_g = !pre_r && Gin != nullptr && sizeof(TS) == 2, pre_c = !pre_r && !pre_g && p.accumulate;
         auto side_load = [&](int it) -> f32x4 {
             const int m = m0 + row_lo + rr + it * RPI;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -268,14 +277,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 if constexpr (PD < NIT) { if (it + PD < NIT && (pre_r || pre_c || pre_g)) side[it % PD] = side_load(it + PD); }
                 if (m < p.M) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
-                    v = v * p.alpha + bv;
+                    v = v * alpha + bv;
                     if (Cpre && !(p.act & 2)) st4(Cpre + (long)m * p.ld_pre + n, v);
                     if ((p.act & 3) == 3) {                     // GELU out, gelu' to C_pre
                         f32x4 d;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<T>(v[e], y, dy); v[e] = y; d[e] = dy; }
+                        for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<TS>(v[e], y, dy); v[e] = y; d[e] = dy; }
                         if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, d);
-                    } else if (p.act & 1) { v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]); }
+                    } else if (p.act & 1) { v[0] = gelu_t<TS>(v[0]); v[1] = gelu_t<TS>(v[1]); v[2] = gelu_t<TS>(v[2]); v[3] = gelu_t<TS>(v[3]); }
                     if (Gin) {
                         f32x4 u;
                         if (pre_g) {
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                         }
                         else u = ld4(Gin + (long)m * p.ld_gelu + n);
                         if (p.act & 4) v *= u;                  // the side input already is gelu'(pre-activation)
-                        else { v[0] *= gelu_grad_t<T>(u[0]); v[1] *= gelu_grad_t<T>(u[1]); v[2] *= gelu_grad_t<T>(u[2]); v[3] *= gelu_grad_t<T>(u[3]); }
+                        else { v[0] *= gelu_grad_t<TS>(u[0]); v[1] *= gelu_grad_t<TS>(u[1]); v[2] *= gelu_grad_t<TS>(u[2]); v[3] *= gelu_grad_t<TS>(u[3]); }
                     }
                     if (pre_r) v += sv;
                     else if (R) v += ld4(R + (long)m * p.ld_resid + n);
@@ -619,9 +628,10 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!a || !a->A || !a->B || !a->C) return TAV_ERR_NULL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return TAV_ERR_SHAPE;
-    const int es = a->in_dtype == TAV_BF16 ? 2 : 4;
-    if (a->in_dtype != TAV_BF16 && a->in_dtype != TAV_F32) return TAV_ERR_DTYPE;
+    const int es = a->in_dtype == TAV_FP8 ? 1 : (a->in_dtype == TAV_BF16 ? 2 : 4);
+    if (a->in_dtype != TAV_BF16 && a->in_dtype != TAV_F32 && a->in_dtype != TAV_FP8) return TAV_ERR_DTYPE;
     if (a->in_dtype == TAV_F32 && a->out_dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if (a->out_dtype != TAV_F32 && a->out_dtype != TAV_BF16) return TAV_ERR_DTYPE;
     if ((a->K * es) % 128 != 0) return TAV_ERR_SHAPE;      // K-tile = 128 bytes
     if ((a->M * a->lda + a->K) * es >= (1ll << 32) || (a->N * a->ldb + a->K) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets per (zb, zg) slice
     if (a->N % 4 != 0) return TAV_ERR_SHAPE;
@@ -637,12 +647,13 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     const int nzb = a->nzb > 0 ? a->nzb : 1;
     p.a_zb = a->a_zb; p.a_zg = a->a_zg; p.b_zb = a->b_zb; p.b_zg = a->b_zg; p.c_zb = a->c_zb; p.c_zg = a->c_zg; p.bias_zg = a->bias_zg;
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
+    p.sa = a->in_dtype == TAV_FP8 ? a->a_dequant : nullptr; p.sb = a->in_dtype == TAV_FP8 ? a->b_dequant : nullptr;
     p.tiles_n = (p.N + 127) / 128;
     // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
     int tm = a->tile_m_hint & 31;                            // 2/3/4: 64/96/128 x 128 tiles (4 waves); 8: 256 x 128, 16: 256 x 256 (8 waves)
     int nst = (a->tile_m_hint >> 5) & 7;                     // tuning: LDS ring depth 2..4 (0 = let the library choose)
-    if (a->in_dtype != TAV_BF16 && (tm == 8 || tm == 16)) tm = 4;
-    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K, nzb * p.nzg, a->in_dtype == TAV_BF16,
+    if (a->in_dtype == TAV_F32 && (tm == 8 || tm == 16)) tm = 4;
+    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K * es / 2, nzb * p.nzg, a->in_dtype != TAV_F32,
                                                                         ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0));
     const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
     p.tiles_m = (p.M + bm - 1) / bm;
@@ -655,6 +666,7 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     else if (tm == 16) nst = 2;
     else if (nst < 2 || nst > 4) nst = (wgs <= 256 && a->in_dtype == TAV_BF16) ? 4 : 2;
     if (a->in_dtype != TAV_BF16) nst = 2;
+    if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
     dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
     const size_t lds = (size_t)nst * (bm + bn) * 128;        // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
 #define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                                 \
@@ -671,7 +683,15 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                               \
         else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                             \
     } while (0)
-    if (a->in_dtype == TAV_BF16) {
+    if (a->in_dtype == TAV_FP8) {
+        if (tm == 16) {
+            if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8>), grid, block, lds, stream, p);
+        } else {
+            if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 4, 4>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
+        }
+    } else if (a->in_dtype == TAV_BF16) {
         if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
         else TAV_NT_LAUNCH(bf16, float);
     } else {

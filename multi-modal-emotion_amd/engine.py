@@ -27,12 +27,15 @@ def bump_weight_epoch():
 
 class Policy:
     def __init__(self, name="bf16"):
-        name = {"bfloat16": "bf16", "float32": "fp32", "f32": "fp32"}.get(name, name)
-        if name not in ("bf16", "fp32"):
+        name = {"bfloat16": "bf16", "float32": "fp32", "f32": "fp32", "float8": "fp8", "e4m3": "fp8"}.get(name, name)
+        if name not in ("bf16", "fp32", "fp8"):
             raise ValueError(f"unknown precision policy {name!r}")
         self.name = name
-        self.lp = torch.bfloat16 if name == "bf16" else torch.float32
+        # "fp8" (BASELINE config 5): the four linear layers of every transformer block (forward, dgrad, wgrad) run on e4m3 operands with
+        # per-tensor scales; everything else -- attention, normalisation, front-ends, residual streams, gradients -- is the bf16 policy
+        self.lp = torch.float32 if name == "fp32" else torch.bfloat16
         self.f32 = name == "fp32"
+        self.fp8 = name == "fp8"
 
 
 class WeightCache:
@@ -123,6 +126,14 @@ class WeightCache:
             ops.cast_weights_multi(aux[0], aux[1], aux[2])       # one workgroup per 32x32 tile of the largest tensor
         self.d[key] = (ver, val, aux, self._refs(params))
         return val
+
+    def layer_fp8(self, wq, wk, wv, bq, bk, bv, wo, w1, w2):
+        """e4m3 operands of one transformer layer (per-tensor scales): (Wqkv, Wo, W1, W2) as ops.Fp8 with both the [N, K] copy (forward) and
+        the transposed [K, N_pad] copy (dgrad), quantised from the fused bf16 operands of layer()."""
+        def build():
+            wqkv, _, _, wo_n, _, w1_n, _, w2_n, _ = self.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+            return tuple(ops.fp8_quantize(w, want_t=True) for w in (wqkv, wo_n, w1_n, w2_n))
+        return self._get(("layer_fp8", id(wq)), (wq, wk, wv, wo, w1, w2), build)
 
     def conv(self, w):
         """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], dgrad operand [k*ci, co])."""
@@ -297,8 +308,110 @@ class EncoderLayerFn(torch.autograd.Function):
         return (g0, None, None, None, None, *grads)
 
 
+class EncoderLayerFp8Fn(torch.autograd.Function):
+    """EncoderLayerFn with the four linear layers on e4m3 operands (Policy("fp8"), BASELINE config 5).  Each GEMM input (LayerNorm output,
+    attention output, GELU output, and in the backward the four incoming gradients) is quantised once per use with its own per-tensor
+    scale (ops.fp8_quantize: amax -> scale on the device -> e4m3 copy + transposed copy); forward and dgrad read the row-major copies, the
+    weight gradients are NT GEMMs of the transposed copies (ops.wgrad_fp8).  Attention, LayerNorm, residual adds and all statistics are
+    exactly those of the bf16 policy.  What is saved for the backward are the fp8 transposed activations, not their bf16 originals."""
+
+    @staticmethod
+    def forward(ctx, x, x_lp, key_mask, ectx, spec, *params):
+        pol, cache = ectx.pol, ectx.cache
+        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
+        B, S, nh = spec.B, spec.S, spec.nheads
+        H = nh * 64
+        bqkv = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)[2]
+        wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        x = _c(x)
+        if spec.pre_ln:
+            _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
+        else:
+            a = x_lp if x_lp is not None else _to_lp(pol, x)
+            mean1 = rstd1 = None
+        a8 = ops.fp8_quantize(a, want_t=True)
+        qkv = ops.gemm_nt_fp8(a8, wqkv8, bias=bqkv)
+        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        o8 = ops.fp8_quantize(o, want_t=True)
+        y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
+        if spec.pre_ln:
+            x1 = y1
+            _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
+        else:
+            x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
+        c8 = ops.fp8_quantize(c, want_t=True)
+        h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
+        h8 = ops.fp8_quantize(h, want_t=True)
+        y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
+        if spec.pre_ln:
+            x2, x2_lp = y2, None
+        else:
+            x2, x2_lp, mean2, rstd2 = _ln_fwd(pol, y2, ln2_w, ln2_b, spec.eps, need_f32=True)
+        ctx.ectx, ctx.spec = ectx, spec
+        ctx.set_materialize_grads(False)
+        ctx.has = [p is not None for p in params]
+        ctx.rows = a.shape[0]
+        corr, o_soft = aux
+        ctx.save_for_backward(x if spec.pre_ln else None, qkv, o, lse, corr, o_soft, y1, u, y2 if not spec.pre_ln else None, mean1, rstd1, mean2, rstd2, key_mask,
+                              a8.qt, a8.scales, o8.qt, o8.scales, c8.qt, c8.scales, h8.qt, h8.scales, *params)
+        if x2_lp is None:
+            x2_lp = x2.new_empty(0)
+        ctx.mark_non_differentiable(x2_lp)
+        return x2, x2_lp
+
+    @staticmethod
+    def backward(ctx, g2, _g_lp):
+        pol, cache, spec = ctx.ectx.pol, ctx.ectx.cache, ctx.spec
+        sv = ctx.saved_tensors
+        x, qkv, o, lse, corr, o_soft, y1, u, y2, mean1, rstd1, mean2, rstd2, key_mask = sv[:14]
+        a_t, a_s, o_t, o_s, c_t, c_s, h_t, h_s = sv[14:22]
+        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[22:]
+        B, S, nh = spec.B, spec.S, spec.nheads
+        H, F, M = nh * 64, w1.shape[0], ctx.rows
+        wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        a8, o8, c8, h8 = (ops.Fp8(None, t, s, M, t.shape[0]) for t, s in ((a_t, a_s), (o_t, o_s), (c_t, c_s), (h_t, h_s)))
+
+        def dgrad(dy8, w8, **kw):            # dY [M, N] x W [N, K] -> [M, K]: the NT GEMM against the transposed copy W^T [K, N_pad]
+            return ops.gemm_nt(dy8.q, w8.qt[:, :w8.rows], a_dequant=dy8.dequant, b_dequant=w8.dequant, **kw)
+
+        g2 = _c(g2)
+        if spec.pre_ln:
+            hint = _hint_take(g2)
+            dy2, dy2_lp = g2, (hint if hint is not None else _to_lp(pol, g2))
+            dg2 = db2 = None
+        else:
+            dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
+        dy28 = ops.fp8_quantize(dy2_lp, want_t=True)
+        du = dgrad(dy28, w28, gelu_in=u, act=4)
+        du8 = ops.fp8_quantize(du, want_t=True)
+        if spec.pre_ln:
+            dc = dgrad(du8, w18, out_dtype=torch.float32)
+            g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
+            dy1, dy1_lp = g1, g1_lp
+        else:
+            g1 = dgrad(du8, w18, resid=dy2, out_dtype=torch.float32)
+            dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
+        dy18 = ops.fp8_quantize(dy1_lp, want_t=True)
+        do = dgrad(dy18, wo8)
+        dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
+                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        dqkv8 = ops.fp8_quantize(dqkv, want_t=True)
+        if spec.pre_ln:
+            da = dgrad(dqkv8, wqkv8, out_dtype=torch.float32)
+            g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON)
+            _hint_set(g0, g0_lp)
+        else:
+            g0 = dgrad(dqkv8, wqkv8, resid=dy1, out_dtype=torch.float32)
+        dW2, dW1, dWo, dWqkv = ops.wgrad_fp8(dy28, h8), ops.wgrad_fp8(du8, c8), ops.wgrad_fp8(dy18, o8), ops.wgrad_fp8(dqkv8, a8)
+        dB2, dB1, dBo, dBqkv = ops.colsum(dy2_lp), ops.colsum(du), ops.colsum(dy1_lp), ops.colsum(dqkv)
+        grads = [dg1, db1, dWqkv[:H], dBqkv[:H], dWqkv[H:2 * H], dBqkv[H:2 * H], dWqkv[2 * H:], dBqkv[2 * H:], dWo, dBo, dg2, db2, dW1, dB1, dW2, dB2]
+        grads = [g if has else None for g, has in zip(grads, ctx.has)]
+        return (g0, None, None, None, None, *grads)
+
+
 def encoder_layer(ectx, spec, x, x_lp, key_mask, params):
-    x2, x2_lp = EncoderLayerFn.apply(x, x_lp, key_mask, ectx, spec, *params)
+    fn = EncoderLayerFp8Fn if ectx.pol.fp8 else EncoderLayerFn
+    x2, x2_lp = fn.apply(x, x_lp, key_mask, ectx, spec, *params)
     return x2, (x2_lp if x2_lp.numel() else None)
 
 

@@ -47,6 +47,9 @@ class PreFormer(nn.Module):
         self.videomae = VideoEncoder(cfg["video"])
         self.wav_2_768 = nn.Linear(Ha, 768)
         nn.init.xavier_normal_(self.wav_2_768.weight)
+        if cfg["video"]["hidden"] != 768:                   # BASELINE config 5 (videomae-large): the bridge the audio branch already has
+            self.vid_2_768 = nn.Linear(cfg["video"]["hidden"], 768)
+            nn.init.xavier_normal_(self.vid_2_768.weight)
         self.check_shapes = 1
 
     # -- reference helpers, same names (models/tav.py:308-342) --
@@ -88,6 +91,12 @@ class PreFormer(nn.Module):
         if audio_mask is not None:
             audio_mask = self._get_feature_vector_attention_mask(Sa, audio_mask.to(dev))     # :355 bool [B, Sa]
 
+        def video_frontend():
+            xv, nv = self.videomae.embed(video_embeds, ~visual_mask, n_visual_true)    # :368
+            if hasattr(self, "vid_2_768"):
+                xv = E.LinearFn.apply(xv, None, self.vid_2_768.weight, self.vid_2_768.bias, None, ectx, True)
+            return xv, nv
+
         def audio_frontend():
             feats = self.wav2vec2.feature_extractor_fwd(audio_features)                 # :352  [B, Sa, 512]
             hidden = self.wav2vec2.feature_projection_fwd(feats)                        # :356  f32 [B*Sa, Ha]
@@ -110,7 +119,7 @@ class PreFormer(nn.Module):
                 x_audio = audio_frontend()
             with torch.cuda.stream(s_v):
                 s_v.wait_event(ev)
-                x_video, Nv = self.videomae.embed(video_embeds, ~visual_mask, n_visual_true)   # :368
+                x_video, Nv = video_frontend()
         if input_ids is not None:
             input_ids = input_ids.to(dev)
             x_text, _ = self.bert.embed(input_ids)                                      # :349
@@ -122,7 +131,7 @@ class PreFormer(nn.Module):
                 ten.record_stream(main)
         else:
             x_audio = audio_frontend()
-            x_video, Nv = self.videomae.embed(video_embeds, ~visual_mask, n_visual_true)
+            x_video, Nv = video_frontend()
         parts += [x_audio, x_video]
         tav = E.ConcatSeqFn.apply(B, *parts)                                            # :372-375
 
@@ -171,6 +180,9 @@ class TAVForMAE(nn.Module):
         self.videomae = VideoEncoder(cfg["video"])
         self.wav_2_768_2 = nn.Linear(Ha, 768)
         nn.init.xavier_normal_(self.wav_2_768_2.weight)
+        if cfg["video"]["hidden"] != 768:
+            self.vid_2_768_2 = nn.Linear(cfg["video"]["hidden"], 768)
+            nn.init.xavier_normal_(self.vid_2_768_2.weight)
         self._drop_calls = 0
 
     def randomize_model(self, model):
@@ -194,6 +206,12 @@ class TAVForMAE(nn.Module):
         audio_features, video_embeds = audio_features.to(dev, torch.float32), video_embeds.to(dev, torch.float32)
         visual_mask, input_ids, text_attention_mask = visual_mask.to(dev), input_ids.to(dev), text_attention_mask.to(dev)
 
+        def video_branch():
+            v, sv = self.videomae(video_embeds, visual_mask, nkeep)                      # :480
+            if hasattr(self, "vid_2_768_2"):
+                v = E.LinearFn.apply(v, None, self.vid_2_768_2.weight, self.vid_2_768_2.bias, None, ectx, True)
+            return v, sv
+
         def audio_branch():
             a, a_lp, sa = self.wav2vec2(audio_features)                                  # :476
             return E.LinearFn.apply(a, a_lp if not ectx.pol.f32 else None, self.wav_2_768_2.weight, self.wav_2_768_2.bias, None, ectx, True), sa   # :478
@@ -210,7 +228,7 @@ class TAVForMAE(nn.Module):
             runtime.share_with(s_txt, input_ids, text_attention_mask)
             with torch.cuda.stream(s_vid):
                 s_vid.wait_event(ev)
-                vid, Sv = self.videomae(video_embeds, visual_mask, nkeep)                # :480
+                vid, Sv = video_branch()
             with torch.cuda.stream(s_aud):
                 s_aud.wait_event(ev)
                 aud, Sa = audio_branch()
@@ -219,7 +237,7 @@ class TAVForMAE(nn.Module):
                 _, t = self.bert(input_ids, text_attention_mask)                         # :485
         else:
             aud, Sa = audio_branch()
-            vid, Sv = self.videomae(video_embeds, visual_mask, nkeep)
+            vid, Sv = video_branch()
             _, t = self.bert(input_ids, text_attention_mask)
         av = E.EmbedAddFn.apply(hidden_states.to(dev).reshape(B * Sf, 768), pos_embed.to(dev).reshape(-1).contiguous(), self.embedding.weight)   # :474
         av = self.random_mae_encoder(av.view(B, Sf, 768), attention_mask.to(dev))       # :487 (fusion branch stays on the caller's stream)

@@ -35,26 +35,27 @@ def profile_start(kind):
     _prof = {"kind": kind, "ev": []}
 
 
-def profile_stop():
-    """-> (algorithmic FLOPs, seconds inside the kernels, launches) since profile_start()."""
+def profile_stop(select="bf16"):
+    """-> (algorithmic FLOPs, seconds inside the kernels, launches) of the launches with `select` operands ("bf16" / "fp8") since profile_start()."""
     global _prof
     torch.cuda.synchronize()
-    ev, nbytes, _prof = _prof["ev"], _prof.get("bytes", 0.0), None
-    secs = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) * 1e-3
-    profile_stop.algorithmic_bytes = nbytes          # operands + output once each (the minimum the launches could move)
-    return sum(f for _, _, f in ev), secs, len(ev)
+    ev, _prof = [e for e in _prof["ev"] if e[3] == select], None
+    secs = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in ev) * 1e-3
+    profile_stop.algorithmic_bytes = sum(e[4] for e in ev)          # operands + output once each (the minimum the launches could move)
+    return sum(e[2] for e in ev), secs, len(ev)
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None, want_pre=False, out=None,
             accumulate=False, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None, tile_m=0):
-    """C = epi(alpha * A @ B^T).  Plain use: a [M,K], b [N,K] contiguous.  Strided/batched use: pass sizes/strides."""
+            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None, tile_m=0, a_dequant=None, b_dequant=None):
+    """C = epi(alpha * A @ B^T).  Plain use: a [M,K], b [N,K] contiguous.  Strided/batched use: pass sizes/strides.
+    fp8 operands (torch.float8_e4m3fn): pass their dequantisation scalars (Fp8.dequant) and an explicit out_dtype."""
     if M is None:
         M, K = a.shape[-2], a.shape[-1]
         N = b.shape[-2]
         lda, ldb = a.stride(-2), b.stride(-2)
-    out_dtype = out_dtype or a.dtype
+    out_dtype = out_dtype or (torch.bfloat16 if a.dtype == torch.float8_e4m3fn else a.dtype)
     if out is None:
         out = torch.empty(out_shape or (M, N), dtype=out_dtype, device=a.device)
     if ldc is None:
@@ -71,20 +72,21 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
     g.a_zb, g.a_zg, g.b_zb, g.b_zg, g.c_zb, g.c_zg, g.bias_zg = a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg
     g.in_dtype, g.out_dtype, g.act, g.accumulate, g.alpha = dt(a), dt(out), act, int(accumulate), alpha
     g.tile_m_hint = tile_m
+    g.a_dequant, g.b_dequant = ptr(a_dequant), ptr(b_dequant)
     if bias is not None:
         assert bias.dtype == torch.float32
     if resid is not None:
         assert resid.dtype == torch.float32
     if gelu_in is not None:
-        assert gelu_in.dtype == a.dtype
-    if _prof is not None and _prof["kind"] == "gemm_nt" and a.dtype == torch.bfloat16:
+        assert gelu_in.dtype == (torch.bfloat16 if a.dtype == torch.float8_e4m3fn else a.dtype)
+    if _prof is not None and _prof["kind"] == "gemm_nt" and a.dtype in (torch.bfloat16, torch.float8_e4m3fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
         e1.record()
         nz = max(nzb, 1) * max(nzg, 1)
-        _prof["ev"].append((e0, e1, 2.0 * M * N * K * nz))
-        _prof["bytes"] = _prof.get("bytes", 0.0) + nz * ((M * K + N * K) * a.element_size() + M * N * (4 if out_dtype == torch.float32 else 2))
+        _prof["ev"].append((e0, e1, 2.0 * M * N * K * nz, "bf16" if a.dtype == torch.bfloat16 else "fp8",
+                            nz * ((M * K + N * K) * a.element_size() + M * N * (4 if out_dtype == torch.float32 else 2))))
     else:
         check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return (out, pre) if want_pre else out
@@ -137,6 +139,60 @@ def gemm_tn_grouped(pairs, want_bias=True):
         outs.append((dW, db))
     check(lib().tav_gemm_tn_grouped(probs, n, rows, dt(pairs[0][0]), stream()), "gemm_tn_grouped")
     return outs
+
+
+# ---------------------------------------------------------------------------------------------- fp8 operands (BASELINE config 5)
+FP8 = torch.float8_e4m3fn
+FP8_KPAD = 1024        # the token axis of a transposed copy is padded to a multiple of this (8 K-splits of whole 128-byte K-tiles)
+
+
+class Fp8:
+    """A per-tensor-scaled e4m3 copy of a 2-D activation / gradient / weight: q [rows, cols] (the NT GEMM's A or B operand), optionally
+    qt [cols, rows_pad] (the same values transposed, token axis zero padded: the operand of the weight-gradient GEMM), and the device
+    scalars (scales[0] = 448/amax, scales[1] = amax/448 = `dequant`)."""
+    __slots__ = ("q", "qt", "scales", "rows", "cols")
+
+    def __init__(self, q, qt, scales, rows, cols):
+        self.q, self.qt, self.scales, self.rows, self.cols = q, qt, scales, rows, cols
+
+    @property
+    def dequant(self):
+        return self.scales[1:2]
+
+
+def fp8_quantize(x, *, want_q=True, want_t=False):
+    """x [rows, cols] f32 / bf16 (row stride arbitrary) -> Fp8.  Two launches for the absolute maximum, one for the copies; the scale
+    stays on the device."""
+    rows, cols = x.shape
+    scales = torch.empty(3, dtype=torch.float32, device=x.device)
+    part = workspace("fp8_amax", lib().tav_fp8_amax_partials(rows, cols), x.device)
+    check(lib().tav_fp8_amax(ptr(x), dt(x), rows, cols, x.stride(0), ptr(part), ptr(scales), stream()), "fp8_amax")
+    q = torch.empty(rows, cols, dtype=FP8, device=x.device) if want_q else None
+    rows_pad = (rows + FP8_KPAD - 1) // FP8_KPAD * FP8_KPAD
+    qt = torch.empty(cols, rows_pad, dtype=FP8, device=x.device) if want_t else None
+    check(lib().tav_fp8_quantize(ptr(x), dt(x), rows, cols, x.stride(0), ptr(scales), ptr(q), cols, ptr(qt), rows_pad, rows_pad, stream()), "fp8_quantize")
+    return Fp8(q, qt, scales, rows, cols)
+
+
+def gemm_nt_fp8(a8, b8, **kw):
+    """epi(A @ B^T) on two Fp8 operands (their .q copies)."""
+    return gemm_nt(a8.q, b8.q, a_dequant=a8.dequant, b_dequant=b8.dequant, **kw)
+
+
+def wgrad_fp8(dy8, x8, nsplit=8):
+    """dW [N1, N2] f32 = dY^T X for two Fp8 tensors over the same token axis, as the NT GEMM of their transposed copies: M = N1, N = N2,
+    K = padded tokens split into `nsplit` z-slices that write f32 slabs, summed in a fixed order by tav_splitk_reduce."""
+    at, bt = dy8.qt, x8.qt
+    N1, Kp = at.shape
+    N2 = bt.shape[0]
+    assert bt.shape[1] == Kp and Kp % (128 * nsplit) == 0
+    kc = Kp // nsplit
+    slabs = workspace("fp8_wgrad_slabs", nsplit * N1 * N2, at.device)
+    gemm_nt(at, bt, out=slabs.view(-1)[:nsplit * N1 * N2].view(nsplit * N1, N2), out_dtype=torch.float32, M=N1, N=N2, K=kc, lda=Kp, ldb=Kp, ldc=N2,
+            nzb=nsplit, a_zb=kc, b_zb=kc, c_zb=N1 * N2, a_dequant=dy8.dequant, b_dequant=x8.dequant)
+    out = torch.empty(N1, N2, dtype=torch.float32, device=at.device)
+    check(lib().tav_splitk_reduce(ptr(slabs), ptr(out), nsplit, N1 * N2, 0, stream()), "splitk_reduce")
+    return out
 
 
 def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):

@@ -318,6 +318,8 @@ def preformer_forward(sd, cfg, input_ids, audio_features, video_embeds, text_mas
     emb_audio = _ln(sd, "wav2vec2.encoder.layer_norm", emb_audio, cfg["audio"]["eps"])                # :361
     emb_audio = _lin(sd, "wav_2_768", emb_audio)                                                      # :363
     emb_video = videomae_embeddings(sd, "videomae.embeddings", cfg["video"], video_embeds, ~visual_mask)            # :368
+    if cfg["video"]["hidden"] != 768:        # BASELINE config 5 (videomae-large): Linear(1024, 768), the analogue of wav_2_768 at :363 (no reference line)
+        emb_video = _lin(sd, "vid_2_768", emb_video)
     tav = torch.concat((emb_text, emb_audio, emb_video), dim=1)                                       # :372
     B = tav.shape[0]
     St, Sa, Sv = emb_text.shape[1], emb_audio.shape[1], emb_video.shape[1]
@@ -336,7 +338,10 @@ def tavformae_forward(sd, cfg, input_ids, text_attention_mask, audio_features, v
     av = hidden_states + sd["embedding.weight"][pos_embed]                                            # :474
     aud = w2v2_model(sd, "wav2vec2", cfg["audio"], audio_features)                                    # :476
     aud = torch.mean(_lin(sd, "wav_2_768_2", aud), dim=1)                                             # :478
-    vid = torch.mean(videomae_model(sd, "videomae", cfg["video"], video_embeds, visual_mask), dim=1)  # :480-481
+    vid = videomae_model(sd, "videomae", cfg["video"], video_embeds, visual_mask)                    # :480
+    if cfg["video"]["hidden"] != 768:        # config 5: Linear(1024, 768), the analogue of wav_2_768_2 at :478 (no reference line)
+        vid = _lin(sd, "vid_2_768_2", vid)
+    vid = torch.mean(vid, dim=1)                                                                      # :481
     _, t = text_encoder(sd, "bert", cfg["text"], input_ids, text_attention_mask)                      # :485
     t = _ln(sd, "bert_norm", t, 1e-5)                                                                 # :486
     av = fusion_encoder(sd, "random_mae_encoder", av, attention_mask, cfg["fusion"])                  # :487

@@ -299,6 +299,23 @@ def main():
             out[f"{name}_{tag}_loss"] = np.array([ls.item()])
             out[f"{name}_{tag}_gradnorm"] = np.array([gn2])
 
+    # ---- 5. BASELINE config 5 geometry: VideoMAE-large widths (1024 / 16 heads / 4096) on 32 frames, tiny depth and image --------------------
+    vl = dict(layers=2, hidden=1024, heads=16, inter=4096, frames=32, image=32, patch=16, tubelet=2, eps=1e-12)
+    hf_l, _ = hf_video(vl)
+    batch, _ = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=32, image=32, vocab=1000, pad_id=0, nkeep_fusion=8)
+    sd_l = {"v." + k: v for k, v in hf_l.state_dict().items()}
+    with torch.no_grad():
+        ref_l = hf_l(batch["video_embeds"], batch["visual_mask"])[0]
+        or_l = O.videomae_model(sd_l, "v", vl, batch["video_embeds"], batch["visual_mask"])
+        ref_e = hf_l.embeddings(batch["video_embeds"], ~batch["visual_mask"])
+        or_e = O.videomae_embeddings(sd_l, "v.embeddings", vl, batch["video_embeds"], ~batch["visual_mask"])
+    e = max(rel(or_l, ref_l), rel(or_e, ref_e))
+    worst = max(worst, e)
+    print(f"videomae-large geometry (32 frames): rel err {e:.2e}  tokens {tuple(ref_l.shape)} / fusion tokens {tuple(ref_e.shape)}")
+    out["L_video_mean"] = ref_l.mean(1).numpy()
+    out["L_video_tok0"] = ref_l[:, 0].numpy()
+    out["L_video_embed_fusion"] = ref_e.numpy()
+
     print(f"worst relative difference oracle vs reference-side modules: {worst:.2e}")
     if worst > 2e-4:
         print("ORACLE NOT PINNED")

@@ -84,6 +84,42 @@ def check_gemm_nt_gelu_derivative_pair(dtype, M=300, N=384, K=256, tile_m=0):
     return rs
 
 
+def check_fp8(M=700, N=384, K=1024, tile_m=0):
+    """fp8 path (BASELINE config 5): per-tensor amax scaling, e4m3 quantisation (+ zero-padded transposed copy), the block-scaled MFMA GEMM with
+    every epilogue flavour, and the weight gradient as the NT GEMM of the transposed copies.  References are computed from the DEQUANTISED
+    operands, so the GEMM comparison is exact up to f32 summation order; the quantiser is compared with torch's own e4m3 conversion."""
+    x = _rnd(M, K, dtype=torch.bfloat16, seed=21)
+    w = _rnd(N, K, seed=22, scale=0.05)
+    x8 = ops.fp8_quantize(x, want_t=True)
+    w8 = ops.fp8_quantize(w)
+    amax = x.float().abs().max()
+    rs = [_res("fp8.amax", x8.scales[2:3], amax.reshape(1), 0.0), _res("fp8.scale", x8.scales[0:1], (448.0 / amax).reshape(1), 1e-6)]
+    ref_q = (x.float() * x8.scales[0]).to(torch.float8_e4m3fn).float()
+    rs.append(_res("fp8.quantize_vs_torch", x8.q.float(), ref_q, 0.0))
+    kp = x8.qt.shape[1]
+    rs.append(_res("fp8.quantize_t", x8.qt.float()[:, :M], x8.q.float().t(), 0.0))
+    rs.append(_res("fp8.quantize_t_pad", x8.qt.float()[:, M:].abs().sum().reshape(1), torch.zeros(1, device=DEV), 0.0))
+    xd, wd = x8.q.float() * x8.scales[1], w8.q.float() * w8.scales[1]
+    bias = _rnd(N, seed=23)
+    res = _rnd(M, N, seed=24)
+    y = ops.gemm_nt_fp8(x8, w8, bias=bias, tile_m=tile_m)
+    rs.append(_res(f"fp8.gemm_nt[bf16 out,tm{tile_m}]", y, xd @ wd.t() + bias, 1e-2))
+    y32 = ops.gemm_nt_fp8(x8, w8, bias=bias, resid=res, out_dtype=torch.float32, tile_m=tile_m)
+    rs.append(_res(f"fp8.gemm_nt[f32 out + resid,tm{tile_m}]", y32, xd @ wd.t() + bias + res, 2e-5))
+    h, gp = ops.gemm_nt_fp8(x8, w8, bias=bias, act=3, want_pre=True, tile_m=tile_m)
+    pre = (xd @ wd.t() + bias).requires_grad_(True)
+    (gr,) = torch.autograd.grad(F.gelu(pre).sum(), pre)
+    rs += [_res("fp8.gemm_nt.gelu", h, F.gelu(pre.detach()), 1e-2), _res("fp8.gemm_nt.gelu'", gp, gr, 1e-2)]
+    # rough quantisation error of the whole product against the unquantised one (per-tensor e4m3, K = 1024): a sanity bound, not a parity claim
+    rs.append(_res("fp8.gemm_nt.vs_unquantised", y32, x.float() @ w.t() + bias + res, 3e-2))
+    dy = _rnd(M, N, dtype=torch.bfloat16, seed=25)
+    dy8 = ops.fp8_quantize(dy, want_q=False, want_t=True)
+    dw = ops.wgrad_fp8(dy8, x8)
+    dyd, xdt = dy8.qt.float()[:, :M] * dy8.scales[1], x8.qt.float()[:, :M] * x8.scales[1]
+    rs.append(_res("fp8.wgrad", dw, dyd @ xdt.t(), 2e-5))
+    return rs
+
+
 def check_gemm_tn(dtype, M=1000, N1=256, N2=384, nbatch=1):
     a = _rnd(nbatch * M, N1, dtype=dtype, seed=8)
     b = _rnd(nbatch * M, N2, dtype=dtype, seed=9)
@@ -467,5 +503,6 @@ def all_checks():
         out.append(lambda d=dtype: check_posconv(d))
     out.append(lambda: check_gemm_nt(torch.bfloat16, out_f32=True))
     out += [check_cast_weight, check_colsum, check_text_embed, lambda: check_text_embed(-1), check_patchify,
-            check_pool_head_ce, check_embed_add, check_scatter_deterministic, check_index_safety]
+            check_pool_head_ce, check_embed_add, check_scatter_deterministic, check_index_safety, check_fp8,
+            lambda: check_fp8(M=1000, N=768, K=256, tile_m=16), lambda: check_fp8(M=130, N=132, K=128, tile_m=4)]
     return out

@@ -693,3 +693,66 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
     for (k, pa), (_, pb) in zip(list(model_a.named_parameters()) + list(pre_a.named_parameters()), list(model_b.named_parameters()) + list(pre_b.named_parameters())):
         worst = max(worst, rel(pb, pa))
     assert worst < 1e-6, worst
+
+
+# ---- BASELINE config 5: videomae-large geometry, 32 frames, fp8 GEMM operands ----------------------------------------------------------
+def test_videomae_large_golden_fp32(gpu):
+    """VideoEncoder at the VideoMAE-large widths (1024 / 16 heads / 4096) on 32 frames, fp32 policy, closed-form weights, against the vectors
+    made from the Hugging Face VideoMAEModel (reference models/tav.py:456,480; generator: oracle/validate_vs_reference.py section 5)."""
+    from tav_amd.encoders import VideoEncoder
+    runtime.set_precision("fp32")
+    vl = dict(layers=2, hidden=1024, heads=16, inter=4096, frames=32, image=32, patch=16, tubelet=2, eps=1e-12)
+    enc = cf.fill_module_(VideoEncoder(vl)).cuda()
+    batch, _ = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=32, image=32, vocab=1000, pad_id=0, nkeep_fusion=8)
+    with torch.no_grad():
+        out, S = enc(batch["video_embeds"].cuda(), batch["visual_mask"].cuda())
+        emb, n = enc.embed(batch["video_embeds"].cuda(), (~batch["visual_mask"]).cuda())
+    assert (S, n) == (56, 8)
+    assert rel(out.view(2, S, -1).mean(1), GOLD["L_video_mean"]) < 1e-4
+    assert rel(out.view(2, S, -1)[:, 0], GOLD["L_video_tok0"]) < 1e-4
+    assert rel(emb.view(2, n, -1), GOLD["L_video_embed_fusion"]) < 1e-4
+
+
+@pytest.mark.parametrize("policy,tol", [("fp32", 1e-3), ("bf16", 1e-2), ("fp8", 1e-2)])
+def test_config5_parity_vs_oracle(gpu, policy, tol):
+    """BASELINE config 5 (preset B with videomae-large on 32 frames, Linear(1024, 768) bridges): every width true, depth 2 per stack, 32 frames of
+    64 x 64 pixels (256 tubelet tokens, 17 to the fusion stack).  Logits, loss and global gradient norm against the fp32 CPU oracle on identical
+    seeded weights: fp32 policy 1e-3, bf16 1e-2, and the fp8 policy -- e4m3 operands with per-tensor scales in every transformer block's linear
+    layers, forward, dgrad and wgrad -- 1e-2 as well."""
+    cfg = C.preset("B5")
+    for k in ("text", "audio", "video", "fusion"):
+        cfg[k]["layers"] = 2
+    cfg["video"]["image"] = 64
+    cfg["text"]["vocab"] = 1000
+    runtime.set_precision(policy)
+    torch.manual_seed(0)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    assert "vid_2_768.weight" in pre.state_dict() and "vid_2_768_2.weight" in model.state_dict()
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=32, t_audio=16000, n_visual_true=17)
+    batch = _as_batch(tx, au, vi)
+    sdp = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+    sdm = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, lab.long())
+    o_loss.backward()
+    o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in list(sdp.values()) + list(sdm.values()) if v.requires_grad and v.grad is not None)).item()
+    pre.cuda()
+    model.cuda()
+    _, _, _, logits, loss = _run_product(pre, model, batch, lab)
+    loss.backward()
+    gn = grad_norm(list(pre.parameters()) + list(model.parameters())).item()
+    e = (rel(logits, o_logits), abs(loss.item() - o_loss.item()) / abs(o_loss.item()), abs(gn - o_gn) / o_gn)
+    gmax = max(v.grad.abs().max().item() for v in list(sdp.values()) + list(sdm.values()) if getattr(v, "grad", None) is not None)
+    worst, worst_k = 0.0, None
+    for mod, sdo, tag in ((pre, sdp, "pre"), (model, sdm, "model")):
+        for k, p in mod.named_parameters():
+            og = sdo[k].grad
+            assert (p.grad is None) == (og is None), f"gradient presence differs for {k}"
+            if og is not None:
+                ek = (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax)
+                if ek > worst:
+                    worst, worst_k = ek, f"{tag}.{k}"
+    print(f"[config 5, {policy}] logits {e[0]:.2e} loss {e[1]:.2e} grad-norm {e[2]:.2e} worst tensor {worst:.2e} ({worst_k})")
+    assert max(e) < tol, e
+    assert worst < {"fp32": 1e-3, "bf16": 3e-2, "fp8": 0.15}[policy], (worst, worst_k)

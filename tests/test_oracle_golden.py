@@ -138,3 +138,32 @@ def test_single_and_dual_models_golden(name, tag):
     assert rel(logits.detach(), GOLD[f"{name}_{tag}_logits"]) < 1e-4
     assert abs(loss.item() - GOLD[f"{name}_{tag}_loss"][0]) < 1e-5
     assert abs(gn - GOLD[f"{name}_{tag}_gradnorm"][0]) / GOLD[f"{name}_{tag}_gradnorm"][0] < 1e-4
+
+
+def test_videomae_large_geometry_golden():
+    """BASELINE config 5 geometry (VideoMAE-large widths 1024 / 16 heads / 4096, 32 frames; tiny depth and image): the oracle against the vectors
+    made from the Hugging Face VideoMAEModel the reference calls at models/tav.py:456,480 (oracle/validate_vs_reference.py section 5)."""
+    vl = dict(layers=2, hidden=1024, heads=16, inter=4096, frames=32, image=32, patch=16, tubelet=2, eps=1e-12)
+    shapes = {}
+    H, Fd = vl["hidden"], vl["inter"]
+    shapes["embeddings.patch_embeddings.projection.weight"] = (H, 3, 2, 16, 16)
+    shapes["embeddings.patch_embeddings.projection.bias"] = (H,)
+    for i in range(vl["layers"]):
+        lp = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            shapes[lp + f"attention.attention.{n}.weight"] = (H, H)
+            shapes[lp + f"attention.attention.{n}.bias"] = (H,)
+        shapes[lp + "attention.output.dense.weight"], shapes[lp + "attention.output.dense.bias"] = (H, H), (H,)
+        shapes[lp + "intermediate.dense.weight"], shapes[lp + "intermediate.dense.bias"] = (Fd, H), (Fd,)
+        shapes[lp + "output.dense.weight"], shapes[lp + "output.dense.bias"] = (H, Fd), (H,)
+        for n in ("layernorm_before", "layernorm_after"):
+            shapes[lp + n + ".weight"], shapes[lp + n + ".bias"] = (H,), (H,)
+    sd = {"v." + k: v for k, v in cf.state_dict_for(shapes).items()}
+    batch, _ = cf.batch_for(B=2, S_text=12, T_audio=3200, frames=32, image=32, vocab=1000, pad_id=0, nkeep_fusion=8)
+    with torch.no_grad():
+        out = O.videomae_model(sd, "v", vl, batch["video_embeds"], batch["visual_mask"])
+        emb = O.videomae_embeddings(sd, "v.embeddings", vl, batch["video_embeds"], ~batch["visual_mask"])
+    assert out.shape == (2, 56, 1024) and emb.shape == (2, 8, 1024)
+    assert rel(out.mean(1), GOLD["L_video_mean"]) < 1e-5
+    assert rel(out[:, 0], GOLD["L_video_tok0"]) < 1e-5
+    assert rel(emb, GOLD["L_video_embed_fusion"]) < 1e-5
