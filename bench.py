@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH, help="utterances per step over ALL GPUs (strong scaling: 32/N per rank)")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="> 0: weak-scaling variant, this many utterances on every GPU")
     ap.add_argument("--preset", default="B")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8", "fp8-all"],
                     help="fp8: e4m3 operands (per-tensor scales) in the linear layers of every transformer block, the rest as bf16 (BASELINE config 5)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -397,10 +397,10 @@ def main():
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
-        flops, secs, launches = ops.profile_stop("fp8" if args.dtype == "fp8" else "bf16")
+        flops, secs, launches = ops.profile_stop("fp8" if args.dtype.startswith("fp8") else "bf16")
         runtime.multistream[0] = not args.profile_serial
         ach = flops / max(secs, 1e-9) / 1e12
-        peak = MFMA_PEAK_FP8_TFLOPS if args.dtype == "fp8" else MFMA_PEAK_BF16_TFLOPS
+        peak = MFMA_PEAK_FP8_TFLOPS if args.dtype.startswith("fp8") else MFMA_PEAK_BF16_TFLOPS
     if rank == 0 and not args.no_roofline and args.dtype != "fp32":
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure is the committed rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE summary of this same command (tools/pmc_traffic.py: 2 x FETCH + WRITE averaged over every gemm_nt

@@ -655,6 +655,7 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     if (a->in_dtype == TAV_F32 && (tm == 8 || tm == 16)) tm = 4;
     if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K * es / 2, nzb * p.nzg, a->in_dtype != TAV_F32,
                                                                         ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0));
+    if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
     const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + bn - 1) / bn;
@@ -666,7 +667,6 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     else if (tm == 16) nst = 2;
     else if (nst < 2 || nst > 4) nst = (wgs <= 256 && a->in_dtype == TAV_BF16) ? 4 : 2;
     if (a->in_dtype != TAV_BF16) nst = 2;
-    if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
     dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
     const size_t lds = (size_t)nst * (bm + bn) * 128;        // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
 #define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                                 \

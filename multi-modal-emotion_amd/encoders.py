@@ -90,7 +90,7 @@ class TextEncoder(nn.Module):
             # HF: (1 - mask) * finfo.min added to the scores before softmax (float 0/1 masks accepted)
             key_mask = ((1.0 - attention_mask.to(torch.float32)) * torch.finfo(torch.float32).min).contiguous()
             mode = 1
-        spec = E.LayerSpec(B, S, c["heads"], c["eps"], pre_ln=False, mask_mode=mode)
+        spec = E.LayerSpec(B, S, c["heads"], c["eps"], pre_ln=False, mask_mode=mode, branch="text")
         n = len(self.encoder.layer)
         for i, L in enumerate(self.encoder.layer):
             x = runtime.cut_point("text", i, n, x)
@@ -214,7 +214,7 @@ class AudioEncoder(nn.Module):
         x_lp = None
         if not c["stable_ln"]:
             x, x_lp = E.layer_norm_f32(ectx, x, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, c["eps"])
-        spec = E.LayerSpec(B, T, c["heads"], c["eps"], pre_ln=c["stable_ln"], mask_mode=0)
+        spec = E.LayerSpec(B, T, c["heads"], c["eps"], pre_ln=c["stable_ln"], mask_mode=0, branch="audio")
         n = len(self.encoder.layers)
         for i, L in enumerate(self.encoder.layers):
             x = runtime.cut_point("audio", i, n, x)
@@ -302,7 +302,7 @@ class VideoEncoder(nn.Module):
         """VideoMAEModel(pixel_values, bool_masked_pos)[0] with use_mean_pooling=True (no final LayerNorm)."""
         ectx, c = runtime.ctx(), self.cfg
         x, nkeep = self.embed(video, bool_masked_pos, nkeep)
-        spec = E.LayerSpec(video.shape[0], nkeep, c["heads"], c["eps"], pre_ln=True, mask_mode=0)
+        spec = E.LayerSpec(video.shape[0], nkeep, c["heads"], c["eps"], pre_ln=True, mask_mode=0, branch="video")
         n = len(self.encoder.layer)
         for i, L in enumerate(self.encoder.layer):
             x = runtime.cut_point("video", i, n, x)

@@ -83,7 +83,7 @@ class VideoMAEEncoder(nn.Module):
         if attention_mask is not None:
             key_mask = attention_mask.reshape(B, S).to(torch.float32).contiguous()      # [B,1,1,S] broadcast over heads and queries
             mode = 2
-        spec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode)
+        spec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode, branch="fusion")
         x = hidden_states.reshape(B * S, H)
         all_hidden = () if output_hidden_states else None
         for i, layer in enumerate(self.layer):

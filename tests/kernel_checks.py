@@ -116,7 +116,7 @@ def check_fp8(M=700, N=384, K=1024, tile_m=0):
     dy8 = ops.fp8_quantize(dy, want_q=False, want_t=True)
     dw = ops.wgrad_fp8(dy8, x8)
     dyd, xdt = dy8.qt.float()[:, :M] * dy8.scales[1], x8.qt.float()[:, :M] * x8.scales[1]
-    rs.append(_res("fp8.wgrad", dw, dyd @ xdt.t(), 2e-5))
+    rs.append(_res("fp8.wgrad", dw, dyd @ xdt.t(), 1e-4))
     return rs
 
 

@@ -631,8 +631,9 @@ def test_collate_device_feeds_captured_step(gpu):
 
 def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
     """bench.py's data-parallel step (ddp.GraphedStep: forward + backward cut into segments, one hipGraph each, the bucket all-reduces issued
-    eagerly on the reducer stream in between, optimizer graph last) on the real RCCL backend with ONE rank: after three steps the weights equal
-    those of the plain eager step (forward_backward + update), and the loss sequence matches."""
+    eagerly on the reducer stream in between, optimizer graph last) on the real RCCL backend with ONE rank.  Learning rate 0 keeps the weights
+    fixed, so every replay must reproduce the plain eager step bit for bit: same loss, and every gradient -- read back from the packed,
+    all-reduced buckets the optimizer graph consumes -- equal to the plain backward's; the optimizer graph itself must have run (step counter)."""
     import torch.distributed as dist
     from tav_amd import engine
     from tav_amd.ddp import GraphedStep
@@ -652,7 +653,7 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
         pre.cuda()
         model.cuda()
         monkeypatch.setenv("TAV_DDP_SINGLE_RANK", "1" if ddp else "0")
-        return pre, model, TrainStep(model, pre, CrossEntropyLoss(), lr=1e-3, weight_decay=1e-2, clip=1.0)
+        return pre, model, TrainStep(model, pre, CrossEntropyLoss(), lr=0.0, weight_decay=1e-2, clip=1.0)
 
     created = False
     if not dist.is_initialized():
@@ -663,14 +664,12 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
         with torch.cuda.stream(s):
             inp, lab = synthetic.make_batch(cfg, 2, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")
             pre_a, model_a, plain = build(False)
-            losses_a = []
-            for _ in range(4):
-                losses_a.append(plain.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4).item())
-                plain.update()
+            loss_a = plain.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4).item()
+            ref = [None if p.grad is None else p.grad.clone() for p in plain.params]
             pre_b, model_b, st = build(True)
             assert st.reducer is not None
-            # step 1 eagerly (hook-mode reducer), as bench.py's warm-up does: the optimizer state must exist before the capture
-            losses_b = [st.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4).item()]
+            # one eager step first (hook-mode reducer), as bench.py's warm-up does: the optimizer state must exist before the capture
+            st.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4)
             st.update()
             torch.cuda.synchronize()
             engine.bump_weight_epoch()
@@ -678,21 +677,26 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
             g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4)
             assert g.seg.nseg == 3 and len(g.graphs) == 3          # 4-layer stacks are cut before layers 1 and 3
             assert sum(len(pl) for pl, _ in g.flats) == len(st.opt.state)          # every trained parameter sits in exactly one bucket
-            for _ in range(3):
-                # (the capture itself executed nothing: the first replay is step 2)
-                losses_b.append(g.run().item())
+            steps0 = st.opt.step_count
+            losses = [g.run().item() for _ in range(3)]            # (the capture itself executed nothing)
             torch.cuda.synchronize()
+            assert st.opt.step_count == steps0 + 3
+            index = {id(p): i for i, p in enumerate(st.params)}
+            n_cmp = 0
+            for plist, flat in g.flats:
+                off = 0
+                for p in plist:
+                    got = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                    assert torch.equal(got, ref[index[id(p)]]), f"gradient of parameter #{index[id(p)]} differs"
+                    n_cmp += 1
             st.reducer.remove()
     finally:
         if created:
             dist.destroy_process_group()
-    print("graphed ddp:", g.describe(), losses_a, losses_b)
-    for la, lb in zip(losses_a, losses_b):
-        assert abs(la - lb) <= 1e-6 * abs(la), (losses_a, losses_b)
-    worst = 0.0
-    for (k, pa), (_, pb) in zip(list(model_a.named_parameters()) + list(pre_a.named_parameters()), list(model_b.named_parameters()) + list(pre_b.named_parameters())):
-        worst = max(worst, rel(pb, pa))
-    assert worst < 1e-6, worst
+    print("graphed ddp:", g.describe(), loss_a, losses, n_cmp, "gradients compared")
+    assert all(l == loss_a for l in losses), (loss_a, losses)
+    assert n_cmp == sum(r is not None for r in ref)
 
 
 # ---- BASELINE config 5: videomae-large geometry, 32 frames, fp8 GEMM operands ----------------------------------------------------------
@@ -713,16 +717,17 @@ def test_videomae_large_golden_fp32(gpu):
     assert rel(emb.view(2, n, -1), GOLD["L_video_embed_fusion"]) < 1e-4
 
 
-@pytest.mark.parametrize("policy,tol", [("fp32", 1e-3), ("bf16", 1e-2), ("fp8", 1e-2)])
+@pytest.mark.parametrize("policy,tol", [("fp32", 1e-3), ("bf16", 1e-2), ("fp8", 1e-2), ("fp8-all", 4e-2)])
 def test_config5_parity_vs_oracle(gpu, policy, tol):
-    """BASELINE config 5 (preset B with videomae-large on 32 frames, Linear(1024, 768) bridges): every width true, depth 2 per stack, 32 frames of
-    64 x 64 pixels (256 tubelet tokens, 17 to the fusion stack).  Logits, loss and global gradient norm against the fp32 CPU oracle on identical
-    seeded weights: fp32 policy 1e-3, bf16 1e-2, and the fp8 policy -- e4m3 operands with per-tensor scales in every transformer block's linear
-    layers, forward, dgrad and wgrad -- 1e-2 as well."""
+    """BASELINE config 5 (preset B with videomae-large on 32 frames, Linear(1024, 768) bridges): every width true, the video at its full size (32 x 3 x
+    224 x 224: 3136 tubelet tokens, 2927 in the video encoder, 209 to the fusion stack), depth 2 per stack.  Logits, loss and global gradient norm
+    against the fp32 CPU oracle on identical
+    seeded weights: fp32 policy 1e-3, bf16 1e-2, and the fp8 policy -- e4m3 operands with per-tensor scales in the video encoder's linear layers,
+    forward, dgrad and wgrad (91 % of the FLOPs of this configuration) -- 1e-2 as well.  "fp8-all" (every stack on e4m3, an experiment, not
+    the shipped policy) is held to 4e-2: the un-pooled text token carries e4m3 rounding straight into the logits."""
     cfg = C.preset("B5")
     for k in ("text", "audio", "video", "fusion"):
         cfg[k]["layers"] = 2
-    cfg["video"]["image"] = 64
     cfg["text"]["vocab"] = 1000
     runtime.set_precision(policy)
     torch.manual_seed(0)
@@ -730,13 +735,16 @@ def test_config5_parity_vs_oracle(gpu, policy, tol):
     assert "vid_2_768.weight" in pre.state_dict() and "vid_2_768_2.weight" in model.state_dict()
     synthetic.seeded_init_(pre, 1)
     synthetic.seeded_init_(model, 2)
-    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=32, t_audio=16000, n_visual_true=17)
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=32, t_audio=16000, n_visual_true=209)
     batch = _as_batch(tx, au, vi)
-    sdp = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
-    sdm = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, lab.long())
-    o_loss.backward()
-    o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in list(sdp.values()) + list(sdm.values()) if v.requires_grad and v.grad is not None)).item()
+    if "c5" not in _ORACLE_CACHE:                          # the oracle run (a few seconds of CPU) is shared by the four policies
+        sdp = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in pre.state_dict().items()}
+        sdm = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+        o_logits, o_loss = O.tav_step(sdm, sdp, cfg, batch, lab.long())
+        o_loss.backward()
+        o_gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in list(sdp.values()) + list(sdm.values()) if v.requires_grad and v.grad is not None)).item()
+        _ORACLE_CACHE["c5"] = (sdp, sdm, o_logits.detach(), o_loss.detach(), o_gn)
+    sdp, sdm, o_logits, o_loss, o_gn = _ORACLE_CACHE["c5"]
     pre.cuda()
     model.cuda()
     _, _, _, logits, loss = _run_product(pre, model, batch, lab)
@@ -755,4 +763,4 @@ def test_config5_parity_vs_oracle(gpu, policy, tol):
                     worst, worst_k = ek, f"{tag}.{k}"
     print(f"[config 5, {policy}] logits {e[0]:.2e} loss {e[1]:.2e} grad-norm {e[2]:.2e} worst tensor {worst:.2e} ({worst_k})")
     assert max(e) < tol, e
-    assert worst < {"fp32": 1e-3, "bf16": 3e-2, "fp8": 0.15}[policy], (worst, worst_k)
+    assert worst < {"fp32": 1e-3, "bf16": 3e-2, "fp8": 0.15, "fp8-all": 0.3}[policy], (worst, worst_k)
