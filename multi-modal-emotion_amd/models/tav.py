@@ -66,14 +66,32 @@ class PreFormer(nn.Module):
         return torch.arange(feature_vector_length, device=attention_mask.device)[None, :] < out_len[:, None]
 
     def _mask_hidden_states(self, hidden, B, T, attention_mask, training=False):
-        """SpecAugment along time (models/tav.py:269-306).  Host-side index sampling as in the reference (numpy RNG);
-        only active when train=True, which is outside the parity / benchmark configuration."""
-        mask_prob, mask_len = 0.05, 10                      # Wav2Vec2Config defaults (mask_time_prob / mask_time_length)
+        """SpecAugment along time (reference models/tav.py:269-306 -> HF _compute_mask_indices, wav2vec2:101): per row, `n` spans of
+        mask_time_length frames, n = max(int(mask_time_prob * len / mask_time_length + eps), min_masks) with eps ~ U[0,1), starts drawn without
+        replacement from the row's valid range, the masked frames replaced by `masked_spec_embed`.  The reference samples on the host with
+        numpy; here the same distribution is drawn ON THE DEVICE (torch ops only, no host read), so a training step with train=True stays
+        graph-capturable.  The number of spans a row can take is bounded by the static sequence length; surplus slots are switched off by
+        comparison instead of by shape.  Only active when train=True, which is outside the parity / benchmark configuration."""
+        mask_prob, mask_len, min_masks = 0.05, 10, 2        # Wav2Vec2Config defaults (mask_time_prob / mask_time_length), min_masks as in the reference
         if not training or T < mask_len:
             return hidden
-        from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
-        idx = _compute_mask_indices((B, T), mask_prob=mask_prob, mask_length=mask_len, attention_mask=attention_mask.cpu(), min_masks=2)
-        sel = torch.tensor(idx, device=hidden.device, dtype=torch.bool).reshape(B * T, 1)
+        dev = hidden.device
+        if attention_mask is not None:
+            lens = attention_mask.to(dev).sum(-1).to(torch.float32)                         # frames that are not padding, per row
+        else:
+            lens = torch.full((B,), float(T), device=dev)
+        eps = torch.rand(B, device=dev)
+        n = torch.clamp((mask_prob * lens / mask_len + eps).floor(), min=float(min_masks))
+        n = torch.minimum(n, torch.clamp(((lens - (mask_len - 1)) / 1.0).floor(), min=0.0))  # never more spans than start positions
+        n = torch.minimum(n, torch.full_like(n, float(T // mask_len)))
+        max_spans = max(min_masks, int(mask_prob * T / mask_len + 1.0))                      # static bound (eps < 1)
+        pos = torch.arange(T, device=dev)[None, :]
+        score = torch.rand(B, T, device=dev)
+        score = torch.where(pos < (lens[:, None] - (mask_len - 1)), score, torch.full_like(score, 2.0))   # starts outside the valid range sort last
+        starts = score.argsort(dim=1)[:, :max_spans]                                          # without replacement
+        live = torch.arange(max_spans, device=dev)[None, :] < n[:, None]
+        cover = (pos[:, None, :] >= starts[:, :, None]) & (pos[:, None, :] < starts[:, :, None] + mask_len) & live[:, :, None]
+        sel = cover.any(dim=1).reshape(B * T, 1)
         return torch.where(sel, self.masked_spec_embed.to(hidden.dtype)[None, :], hidden)
 
     def forward(self, input_ids=None, audio_features=None, video_embeds=None, text_mask=None, audio_mask=None, visual_mask=None,

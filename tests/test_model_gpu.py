@@ -565,6 +565,37 @@ def test_unequal_visual_rows_raise_not_fault(gpu):
     assert torch.isfinite(logits).all()
 
 
+def test_specaugment_on_device_is_capturable(gpu):
+    """PreFormer(train=True): the SpecAugment time mask (reference models/tav.py:269-306) is drawn on the device -- no host read -- so the call can
+    be captured into a hipGraph; each replay draws a fresh mask (graph-safe Philox offsets), rows keep their span budget (2 spans of 10 frames at
+    249 frames) and padding frames are never chosen as span starts."""
+    cfg = C.preset("B-tiny")
+    runtime.set_precision("bf16")
+    torch.manual_seed(0)
+    pre = PreFormer(cfg).cuda()
+    (tx, au, vi), _ = synthetic.make_batch(cfg, 3, s_text=16, t_audio=80000, n_visual_true=4, device="cuda")
+    kw = dict(input_ids=tx["input_ids"], audio_features=au["audio_features"], video_embeds=vi["visual_embeds"], text_mask=tx["attention_mask"],
+              audio_mask=au["attention_mask"], visual_mask=vi["attention_mask"], device="cuda", n_visual_true=4)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), torch.no_grad():
+        clean, _, _ = pre(train=False, **kw)
+        pre(train=True, **kw)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            noisy, _, _ = pre(train=True, **kw)
+        outs = []
+        for _ in range(2):
+            g.replay()
+            torch.cuda.synchronize()
+            outs.append(noisy.clone())
+    St, Sa = 16, 249
+    for o in outs:                                           # every row got masked frames (a span also moves its neighbours through the positional conv)
+        assert (o[:, St:St + Sa] != clean[:, St:St + Sa]).any(-1).any(dim=1).all() and torch.isfinite(o).all()
+    assert not torch.equal(outs[0], outs[1])                                                # a new draw per replay
+    assert torch.equal(outs[0][:, :St], clean[:, :St]) and torch.equal(outs[0][:, St + Sa:], clean[:, St + Sa:])   # text / video tokens untouched
+
+
 def test_collate_device_feeds_captured_step(gpu):
     """collate_batch_device builds the batch ON the GPU (padding, audio length mask, equal-count video token mask) and its
     output drives PreFormer + TAVForMAE + loss + backward captured into ONE hipGraph; replaying the graph on a second collated batch (copied into
