@@ -288,7 +288,9 @@ class GraphedStep:
         self.gu = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool(), **mode):
             stepper.update()
-        red.buckets = [(plist, flat) for plist, flat in self.flats]
+        red.buckets = [(plist, flat) for plist, flat in self.flats]          # hook mode, if switched back on, reuses these buckets
+        red._bucket_of = {p: i for i, (plist, _) in enumerate(red.buckets) for p in plist}
+        red._pending, red._streams, red._works = {}, {}, []
 
     def _run_and_pack(self, s):
         plist = [p for p in self.seg.run(s) if p.grad is not None]

@@ -86,7 +86,10 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
         e1.record()
         nz = max(nzb, 1) * max(nzg, 1)
         _prof["ev"].append((e0, e1, 2.0 * M * N * K * nz, "bf16" if a.dtype == torch.bfloat16 else "fp8",
-                            nz * ((M * K + N * K) * a.element_size() + M * N * (4 if out_dtype == torch.float32 else 2))))
+                            # operands, output and every epilogue side tensor once each: the minimum the launch could move
+                            nz * ((M * K + N * K) * a.element_size() + M * N * ((4 if out_dtype == torch.float32 else 2) * (2 if want_pre else 1)
+                                                                                + (4 if resid is not None else 0) + (2 if gelu_in is not None else 0)
+                                                                                + ((4 if out_dtype == torch.float32 else 2) if accumulate else 0)))))
     else:
         check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return (out, pre) if want_pre else out
