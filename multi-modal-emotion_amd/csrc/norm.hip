@@ -134,9 +134,10 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 }
 
 // cap on workgroups of the LN backward (= rows of the dgamma/dbeta partial buffer).  Measured at 11712 x 768: 256 -> 35.5 us,
-// 512 -> 33.9 us, 1024 -> 38.0 us (more partial rows for ln_param_reduce): occupancy is not what limits it.
+// 512 -> 33.9 us, 1024 -> 38.0 us (more partial rows for ln_param_reduce); at 46848 x 768 (batch 32): 256 -> 157 us, 512 -> 106.5 us
+// (4.7 TB/s), 1024 -> 131 us, 2048 -> 136 us: one workgroup per CU keeps too few bytes in flight, four pay for their partial rows.
 #ifndef LN_MAX_BLOCKS
-#define LN_MAX_BLOCKS 256
+#define LN_MAX_BLOCKS 512
 #endif
 static inline int ln_blocks(long rows) {
     long b = (rows + 15) / 16;      // >= 4 rows per wave so the per-lane dgamma/dbeta partials amortise
