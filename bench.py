@@ -99,6 +99,8 @@ def parse_args():
     ap.add_argument("--profile-serial", action="store_true",
                     help="profiling mode: eager launches, every branch on ONE stream, so that a rocprofv3 --kernel-trace --stats of this command sees each "
                          "kernel alone on the device (the condition of the roofline pass); the utterances/s of such a run is not the headline")
+    ap.add_argument("--branch-streams", type=int, default=-1,
+                    help="1: text / audio / video encoders on their own HIP streams beside the fusion stack, 0: everything on one stream, -1: library default")
     ap.add_argument("--ddp-segments", type=int, default=4, help="N > 1: backward graphs per step; bucket i is reduced on a side stream while graph i+1 runs")
     return ap.parse_args()
 
@@ -233,6 +235,8 @@ def main():
     runtime.set_precision(args.dtype)
     if args.profile_serial:
         runtime.multistream[0] = False
+    elif args.branch_streams >= 0:
+        runtime.multistream[0] = bool(args.branch_streams)
     torch.manual_seed(0)
     pre = PreFormer(cfg)
     model = TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg)
@@ -391,6 +395,7 @@ def main():
         if stepper.reducer is not None:
             stepper.reducer.set_manual(False)
         stepper.opt.zero_grad()
+        ms_default = runtime.multistream[0]
         runtime.multistream[0] = False
         eager_step()                                         # shapes may have changed (secondary batch): re-warm
         ops.profile_start("gemm_nt")
@@ -398,7 +403,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         flops, secs, launches = ops.profile_stop("fp8" if args.dtype.startswith("fp8") else "bf16")
-        runtime.multistream[0] = not args.profile_serial
+        runtime.multistream[0] = ms_default
         ach = flops / max(secs, 1e-9) / 1e12
         peak = MFMA_PEAK_FP8_TFLOPS if args.dtype.startswith("fp8") else MFMA_PEAK_BF16_TFLOPS
     if rank == 0 and not args.no_roofline and args.dtype != "fp32":
