@@ -153,9 +153,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(torch, synthetic, cfg, pre, model, protocol):
+def cpu_baseline(torch, synthetic, cfg, pre, model, protocol, gpu_loss=None):
     """Oracle (CPU port of the reference path) fwd + loss + bwd on the host cores of this box, BASELINE.md §3: 2 warm-ups, median of 5.
-    `bounded` times batch 1 only (about 25 s of CPU work: the default bench run must finish in minutes); `full` adds batch 8."""
+    `bounded` times batch 1 only (about 25 s of CPU work: the default bench run must finish in minutes); `full` adds batch 8.
+    The oracle's loss on the batch-1 sample is also compared with the product's on the same weights and inputs (`gpu_loss`, a callable):
+    the timed CPU work doubles as a parity check of the benchmarked build."""
     from oracle import tav_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -167,11 +169,15 @@ def cpu_baseline(torch, synthetic, cfg, pre, model, protocol):
         batch = dict(input_ids=tx["input_ids"], text_mask=tx["attention_mask"], audio_features=au["audio_features"], audio_mask=au["attention_mask"],
                      video_embeds=vi["visual_embeds"], visual_mask=vi["attention_mask"])
         times = []
+        if b == 1 and gpu_loss is not None:
+            check = (gpu_loss(batch, lab), None)
         for it in range(7):
             t0 = time.perf_counter()
             _, loss = O.tav_step(sd_model, sd_pre, cfg, batch, lab.long())
             loss.backward()
             times.append(time.perf_counter() - t0)
+            if b == 1 and gpu_loss is not None and check[1] is None:
+                check = (check[0], float(loss.detach()))
             log(f"cpu baseline b={b} iter {it}: {times[-1]:.2f} s ({cores} threads)")
             for v in list(sd_pre.values()) + list(sd_model.values()):
                 v.grad = None
@@ -181,6 +187,9 @@ def cpu_baseline(torch, synthetic, cfg, pre, model, protocol):
                      "median of 5 after 2 warm-ups (BASELINE.md §3)"}
     if len(res) > 1:
         out["by_batch"] = {str(b): round(v, 4) for b, v in res.items()}
+    if gpu_loss is not None:
+        out["loss_check"] = {"oracle": round(check[1], 6), "libtavhip": round(check[0], 6), "rel_diff": round(abs(check[0] - check[1]) / abs(check[1]), 6),
+                             "note": "same weights, same batch-1 sample; budget 1e-2 (bf16 policy)"}
     return out
 
 
@@ -431,7 +440,16 @@ def main():
     cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t0 = time.time()
-        cpu_ref = cpu_baseline(torch, synthetic, cfg, pre, model, args.cpu_protocol)
+        def gpu_loss(batch, lab):
+            from tav_amd.train_model.tav_train import get_statistics
+            dev_in = [{"input_ids": batch["input_ids"].to(dev), "attention_mask": batch["text_mask"].to(dev)},
+                      {"audio_features": batch["audio_features"].to(dev), "attention_mask": batch["audio_mask"].to(dev)},
+                      {"visual_embeds": batch["video_embeds"].to(dev), "attention_mask": batch["visual_mask"].to(dev)}]
+            with torch.no_grad():
+                ls = get_statistics(dev_in, lab.to(dev), model, pre, CrossEntropyLoss(), None, check="val", epoch=0, n_visual_true=n_true)
+            torch.cuda.synchronize()
+            return float(ls)
+        cpu_ref = cpu_baseline(torch, synthetic, cfg, pre, model, args.cpu_protocol, gpu_loss)
         log(f"cpu baseline: {cpu_ref}  ({time.time() - t0:.1f} s)")
 
     if rank == 0:
