@@ -68,9 +68,12 @@ typedef struct tav_gemm_nt_args {
     float alpha;
     const float* a_dequant; /* in_dtype == TAV_FP8: device scalars (amax/448 of each operand, tav_fp8_amax) multiplied into alpha; NULL = 1 */
     const float* b_dequant;
-    int32_t tile_m_hint;    /* 0 = let the library choose; bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands); bits 5-7: LDS ring depth 2-4 (tuning / tests) */
+    int32_t tile_m_hint;    /* 0 = let the library choose (it may cover the rows with two launches: whole rounds of 256 x 256 tiles, then 128-wide tiles over the rest); bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands), 17 = library's choice of ONE tile for all rows; bits 5-7: LDS ring depth 2-4 (tuning / tests) */
 } tav_gemm_nt_args;
 int tav_gemm_nt(const tav_gemm_nt_args* args, void* stream);
+/* Host-only: the tile plan tav_gemm_nt would use for these arguments (pointers are not read).  *tile as in tile_m_hint; the first
+ * *rows_first rows take it; *tile_rest != 0 means a second launch with that tile covers rows [*rows_first, M). */
+int tav_gemm_nt_schedule(const tav_gemm_nt_args* args, int32_t* tile, int32_t* rows_first, int32_t* tile_rest);
 
 /* GEMM, "TN" (weight gradients): out[n1][perm(n2)] (+)= scale * sum_{z,t} A[z][t][n1] * B[z][t][n2].
  * The token axis is split into `nsplit` chunks that write f32 slabs [nsplit][N1][N2]; a second kernel sums the slabs

@@ -65,6 +65,7 @@ _SIGS = {
     "tav_version": (C.c_int, []),
     "tav_error_string": (C.c_char_p, [C.c_int]),
     "tav_gemm_nt": (C.c_int, [C.POINTER(GemmNTArgs), vp]),
+    "tav_gemm_nt_schedule": (C.c_int, [C.POINTER(GemmNTArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "tav_gemm_tn_splits": (C.c_int, [i64, i64, i64, i64, C.POINTER(i32), C.POINTER(i32)]),
     "tav_gemm_tn": (C.c_int, [C.POINTER(GemmTNArgs), vp]),
     "tav_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTNProblem), i32, i64, i32, vp]),

@@ -596,7 +596,7 @@ using namespace tav;
 // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
 // `epi`: what the epilogue moves and computes besides the plain store -- bit 0: f32 residual (or accumulate) read, bit 1: f32 output,
 // bit 2: GELU (+ second output) or gelu'(side input).
-static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in, int epi) {
+static int nt_small_tile(int M, int N, int nz) {
     const int tiles_n = (N + 127) / 128;
     int tm = 4;
     double best = 1e30;
@@ -605,28 +605,55 @@ static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in, int epi) {
         const double cost = (double)((tiles + 255) / 256) * (c + 0.8);
         if (cost < best - 1e-9) { best = cost; tm = c; }
     }
-    // 256x256 (8 waves, one workgroup per CU) against the 128-wide winner, in microseconds: rounds x (K-tiles x time per K-tile + prologue
-    // and epilogue), constants fitted to tools/gpu_ab.py `tiles` and `layer` at batch 32 (they reproduce its timings within ~5 %).  The big
-    // tile stages half the bytes per FLOP (1.35 PFLOP/s at 4096^3 against 1.15) but nothing on its CU computes while it runs its epilogue,
-    // whereas two 128-wide workgroups per CU overlap one's epilogue with the other's main loop: memory-heavy epilogues (f32 residual in,
-    // f32 out) favour the small tile, plain bf16 outputs the big one.
+    return tm;
+}
+// Fitted launch times in microseconds: rounds x (K-tiles x time per K-tile + prologue and epilogue), constants from tools/gpu_ab.py `tiles`
+// and `layer` at batch 32 (they reproduce its timings within ~5 %).
+static double nt_small_us(int M, int N, double nk, int nz, int tm, int epi) {
+    static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.56, 0.72, 0.85}, fix[5] = {0, 0, 4.2, 4.9, 5.6};
+    const long t = (long)((M + 32 * tm - 1) / (32 * tm)) * ((N + 127) / 128) * nz;
+    // two workgroups per CU hide one's epilogue behind the other's main loop: the residual read costs little after a short K loop
+    const double e = ((epi & 1) ? 2.0 + 0.2 * nk : 0.0) + ((epi & 2) ? 2.0 : 0.0) + ((epi & 4) ? 4.5 : 0.0);
+    return (double)((long)((t + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm] + e * tm / 4.0);
+}
+static double nt_big_round_us(double nk, int epi) {
+    return nk * 1.48 + 9.4 + ((epi & 1) ? 18.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 10.0 : 0.0);
+}
+// Returns the tile for the launch; when `rows_big` is given and a mixed schedule is faster, *rows_big < M is the number of leading rows that
+// take the 256 x 256 tile (whole rounds of 256 workgroups) and *tm_rest the 128-wide tile of a second launch over the remaining rows.
+static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in, int epi, int* rows_big = nullptr, int* tm_rest = nullptr) {
+    int tm = nt_small_tile(M, N, nz);
+    if (rows_big) *rows_big = M;
+    // 256x256 (8 waves, one workgroup per CU) against the 128-wide winner.  The big tile stages half the bytes per FLOP (1.35 PFLOP/s at
+    // 4096^3 against 1.15) but nothing on its CU computes while it runs its epilogue, whereas two 128-wide workgroups per CU overlap one's
+    // epilogue with the other's main loop: memory-heavy epilogues (f32 residual in, f32 out) favour the small tile, plain bf16 outputs the
+    // big one.  A last, partly filled round of big tiles costs a whole round: when the grid is a few rounds long (N = 768 at batch 32:
+    // 2.14 rounds) the rows of that last round go to a second launch with the small tile instead.
     if (bf16_in && M >= 256 && N >= 256) {
-        static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.56, 0.72, 0.85}, fix[5] = {0, 0, 4.2, 4.9, 5.6};
         const double nk = (double)K / 64.0;
-        const long t_small = (long)((M + 32 * tm - 1) / (32 * tm)) * tiles_n * nz;
-        const long t_big = (long)((M + 255) / 256) * ((N + 255) / 256) * nz;
-        const double e_small = ((epi & 1) ? 8.0 : 0.0) + ((epi & 2) ? 5.0 : 0.0) + ((epi & 4) ? 4.5 : 0.0);
-        const double e_big = ((epi & 1) ? 18.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 10.0 : 0.0);
-        const double us_small = (double)((long)((t_small + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm] + e_small * tm / 4.0);
-        const double us_big = (double)((t_big + 255) / 256) * (nk * 1.48 + 9.4 + e_big);
-        if (us_big < 0.98 * us_small) tm = 16;
+        const long tn_big = (N + 255) / 256;
+        const long t_big = (long)((M + 255) / 256) * tn_big * nz;
+        const double us_small = nt_small_us(M, N, nk, nz, tm, epi);
+        const double big_round = nt_big_round_us(nk, epi);
+        const double us_big = (double)((t_big + 255) / 256) * big_round;
+        double us_best = us_small;
+        if (us_big < 0.98 * us_small) { tm = 16; us_best = us_big; }
+        const long full = t_big / 256;
+        if (rows_big && nz == 1 && full >= 1 && t_big % 256 != 0) {
+            const long m_tiles = full * 256 / tn_big;
+            const int rows_a = (int)(m_tiles * 256), m_rest = M - rows_a;
+            if (m_tiles >= 1 && m_rest > 0) {
+                const int tr = nt_small_tile(m_rest, N, 1);
+                const double us_split = (double)((m_tiles * tn_big + 255) / 256) * big_round + nt_small_us(m_rest, N, nk, 1, tr, epi) + 2.0;   // + the seam between two launches
+                if (us_split < 0.97 * us_best) { tm = 16; *rows_big = rows_a; *tm_rest = tr; }
+            }
+        }
     }
     return tm;
 }
 
-extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!a || !a->A || !a->B || !a->C) return TAV_ERR_NULL;
+static int nt_validate(const tav_gemm_nt_args* a, bool need_ptrs) {
+    if (!a || (need_ptrs && (!a->A || !a->B || !a->C))) return TAV_ERR_NULL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return TAV_ERR_SHAPE;
     const int es = a->in_dtype == TAV_FP8 ? 1 : (a->in_dtype == TAV_BF16 ? 2 : 4);
     if (a->in_dtype != TAV_BF16 && a->in_dtype != TAV_F32 && a->in_dtype != TAV_FP8) return TAV_ERR_DTYPE;
@@ -638,6 +665,42 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     const int pk = 16 / es;
     if (a->lda % pk || a->ldb % pk || a->ldc % 4) return TAV_ERR_ALIGN;
     if (a->a_zb % pk || a->a_zg % pk || a->b_zb % pk || a->b_zg % pk || a->c_zb % 4 || a->c_zg % 4) return TAV_ERR_ALIGN;
+    return 0;
+}
+// The tile plan of one call: `tm` for the first `rows_big` rows (all of them unless a mixed schedule wins), `tm_rest` for the others.
+static void nt_plan(const tav_gemm_nt_args* a, int* tm_out, int* rows_big, int* tm_rest) {
+    const int es = a->in_dtype == TAV_FP8 ? 1 : (a->in_dtype == TAV_BF16 ? 2 : 4);
+    const int nz = (int)((a->nzb > 0 ? a->nzb : 1) * (a->nzg > 0 ? a->nzg : 1));
+    int tm = a->tile_m_hint & 31;                            // 2/3/4: 64/96/128 x 128 tiles (4 waves); 8: 256 x 128, 16: 256 x 256 (8 waves); 17: as 0 but one launch
+#ifdef TAV_ABL_NOSPLIT                                       // tools/ab_build.sh: one tile per launch, for same-box A/B of the mixed schedule
+    const bool may_split = false;
+#else
+    const bool may_split = tm == 0 && a->in_dtype == TAV_BF16 && nz == 1;
+#endif
+    *rows_big = (int)a->M; *tm_rest = 4;
+    if (a->in_dtype == TAV_F32 && (tm == 8 || tm == 16)) tm = 4;
+    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4))
+        tm = nt_pick_tile((int)a->M, (int)a->N, (int)(a->K * es / 2), nz, a->in_dtype != TAV_F32,
+                          ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0),
+                          may_split ? rows_big : nullptr, tm_rest);
+    if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
+    *tm_out = tm;
+}
+
+extern "C" int tav_gemm_nt_schedule(const tav_gemm_nt_args* a, int32_t* tile, int32_t* rows_first, int32_t* tile_rest) {
+    if (!tile || !rows_first || !tile_rest) return TAV_ERR_NULL;
+    const int rc = nt_validate(a, false);
+    if (rc != 0) return rc;
+    int tm, rb, tr;
+    nt_plan(a, &tm, &rb, &tr);
+    *tile = tm; *rows_first = rb; *tile_rest = rb < a->M ? tr : 0;
+    return 0;
+}
+
+extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    { const int rc = nt_validate(a, true); if (rc != 0) return rc; }
+    const int es = a->in_dtype == TAV_FP8 ? 1 : (a->in_dtype == TAV_BF16 ? 2 : 4);
     GemmNT p;
     p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C; p.Cpre = (char*)a->C_pre; p.bias = a->bias;
     p.gelu_in = (const char*)a->gelu_in; p.resid = a->resid;
@@ -648,27 +711,23 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     p.a_zb = a->a_zb; p.a_zg = a->a_zg; p.b_zb = a->b_zb; p.b_zg = a->b_zg; p.c_zb = a->c_zb; p.c_zg = a->c_zg; p.bias_zg = a->bias_zg;
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
     p.sa = a->in_dtype == TAV_FP8 ? a->a_dequant : nullptr; p.sb = a->in_dtype == TAV_FP8 ? a->b_dequant : nullptr;
-    p.tiles_n = (p.N + 127) / 128;
-    // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-    int tm = a->tile_m_hint & 31;                            // 2/3/4: 64/96/128 x 128 tiles (4 waves); 8: 256 x 128, 16: 256 x 256 (8 waves)
-    int nst = (a->tile_m_hint >> 5) & 7;                     // tuning: LDS ring depth 2..4 (0 = let the library choose)
-    if (a->in_dtype == TAV_F32 && (tm == 8 || tm == 16)) tm = 4;
-    if (tm != 8 && tm != 16 && (tm < 2 || tm > 4)) tm = nt_pick_tile(p.M, p.N, p.K * es / 2, nzb * p.nzg, a->in_dtype != TAV_F32,
-                                                                        ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0));
-    if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
-    const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
-    p.tiles_m = (p.M + bm - 1) / bm;
-    p.tiles_n = (p.N + bn - 1) / bn;
-    const long wgs = (long)p.tiles_m * p.tiles_n * nzb * p.nzg;
-    // Ring depth.  Large grids run two workgroups per CU and are bound by the L2->LDS intake, where depth changes nothing: 2.
-    // A grid of at most one workgroup per CU (the text / audio / fusion branches' N = 768 GEMMs) is LATENCY bound instead -- a lone
-    // workgroup waits out every DMA round trip -- and has the whole LDS to itself: 4 buffers (3 tiles in flight).
-    if (tm == 8) nst = 3;
-    else if (tm == 16) nst = 2;
-    else if (nst < 2 || nst > 4) nst = (wgs <= 256 && a->in_dtype == TAV_BF16) ? 4 : 2;
-    if (a->in_dtype != TAV_BF16) nst = 2;
-    dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
-    const size_t lds = (size_t)nst * (bm + bn) * 128;        // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
+    const int in_dtype = a->in_dtype, out_dtype = a->out_dtype;
+    const int hint_nst = (a->tile_m_hint >> 5) & 7;         // tuning: LDS ring depth 2..4 (0 = let the library choose)
+    auto launch = [&](GemmNT p, int tm) {
+        int nst = hint_nst;
+        const int bm = tm >= 8 ? 256 : 32 * tm, bn = tm == 16 ? 256 : 128;
+        p.tiles_m = (p.M + bm - 1) / bm;
+        p.tiles_n = (p.N + bn - 1) / bn;
+        const long wgs = (long)p.tiles_m * p.tiles_n * nzb * p.nzg;
+        // Ring depth.  Large grids run two workgroups per CU and are bound by the L2->LDS intake, where depth changes nothing: 2.
+        // A grid of at most one workgroup per CU (the text / audio / fusion branches' N = 768 GEMMs) is LATENCY bound instead -- a lone
+        // workgroup waits out every DMA round trip -- and has the whole LDS to itself: 4 buffers (3 tiles in flight).
+        if (tm == 8) nst = 3;
+        else if (tm == 16) nst = 2;
+        else if (nst < 2 || nst > 4) nst = (wgs <= 256 && in_dtype == TAV_BF16) ? 4 : 2;
+        if (in_dtype != TAV_BF16) nst = 2;
+        dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
+        const size_t lds = (size_t)nst * (bm + bn) * 128;    // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
 #define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                                 \
     do {                                                                                                             \
         if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4, 4>), grid, block, lds, stream, p);         \
@@ -683,21 +742,39 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                               \
         else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                             \
     } while (0)
-    if (a->in_dtype == TAV_FP8) {
-        if (tm == 16) {
-            if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8>), grid, block, lds, stream, p);
+        if (in_dtype == TAV_FP8) {
+            if (tm == 16) {
+                if (out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8>), grid, block, lds, stream, p);
+                else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8>), grid, block, lds, stream, p);
+            } else {
+                if (out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 4, 4>), grid, block, lds, stream, p);
+                else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
+            }
+        } else if (in_dtype == TAV_BF16) {
+            if (out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
+            else TAV_NT_LAUNCH(bf16, float);
         } else {
-            if (a->out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 4, 4>), grid, block, lds, stream, p);
-            else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
+            if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
+            else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4, 4>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4, 4>), grid, block, lds, stream, p);
         }
-    } else if (a->in_dtype == TAV_BF16) {
-        if (a->out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
-        else TAV_NT_LAUNCH(bf16, float);
+    };
+    int tm, rows_big, tm_rest;
+    nt_plan(a, &tm, &rows_big, &tm_rest);
+    if (rows_big < p.M) {
+        // mixed schedule: whole rounds of 256 x 256 tiles over the leading rows, then the 128-wide tile over the rest (same stream, disjoint rows)
+        GemmNT q = p;
+        const long r = rows_big, oes = out_dtype == TAV_F32 ? 4 : 2;
+        q.M = p.M - rows_big;
+        q.A = p.A + r * p.lda * es; q.C = p.C + r * p.ldc * oes;
+        if (p.Cpre) q.Cpre = p.Cpre + r * p.ld_pre * oes;
+        if (p.gelu_in) q.gelu_in = p.gelu_in + r * p.ld_gelu * es;
+        if (p.resid) q.resid = p.resid + r * p.ld_resid;
+        p.M = rows_big;
+        launch(p, 16);
+        launch(q, tm_rest);
     } else {
-        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4, 4>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 2, 2, 4, 4>), grid, block, lds, stream, p);
+        launch(p, tm);
     }
 #undef TAV_NT_LAUNCH
 #undef TAV_NT_LAUNCH_S

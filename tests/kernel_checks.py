@@ -55,6 +55,36 @@ def check_gemm_nt(dtype, M=300, N=256, K=128, bias=True, act=0, resid=True, pre=
     return rs
 
 
+def check_gemm_nt_mixed_schedule(M=46848 + 37, N=768, K=768):
+    """The library may cover a launch's rows with whole rounds of 256 x 256 tiles plus 128-wide tiles over the rest (tav_gemm_nt_schedule).
+    Every output element sums over K in the same order whatever the tile, so the mixed schedule must reproduce the single-tile launch
+    (hint 17) BIT FOR BIT, for each epilogue flavour and every side tensor (bias, residual, second output, gelu' input)."""
+    import ctypes as C
+    dtype = torch.bfloat16
+    a = _rnd(M, K, dtype=dtype, seed=41)
+    b = _rnd(N, K, dtype=dtype, scale=0.1, seed=42)
+    bi = _rnd(N, seed=43)
+    r = _rnd(M, N, seed=44)
+    u = _rnd(M, N, dtype=dtype, seed=45)
+    g = ops.L.GemmNTArgs()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.in_dtype, g.out_dtype, g.nzb, g.nzg = M, N, K, K, K, N, 1, 1, 1, 1
+    t, rf, tr = C.c_int32(), C.c_int32(), C.c_int32()
+    assert ops.lib().tav_gemm_nt_schedule(C.byref(g), C.byref(t), C.byref(rf), C.byref(tr)) == 0
+    split = 0 < rf.value < M and tr.value > 0
+    rs = [(f"gemm_nt.mixed.plan[M{M},N{N},K{K}] is two launches", 0.0 if split else 1.0, 0.0, bool(split))]
+    flavours = [("bias->bf16", dict(bias=bi)), ("bias+resid->f32", dict(bias=bi, resid=r, out_dtype=torch.float32)),
+                ("gelu+pre", dict(bias=bi, act=3, want_pre=True)), ("*gelu'", dict(gelu_in=u, act=4)), ("->f32", dict(out_dtype=torch.float32))]
+    for name, kw in flavours:
+        mixed = ops.gemm_nt(a, b, tile_m=0, **kw)
+        single = ops.gemm_nt(a, b, tile_m=17, **kw)
+        mixed, single = (mixed if isinstance(mixed, tuple) else (mixed,)), (single if isinstance(single, tuple) else (single,))
+        same = all(torch.equal(x, y) for x, y in zip(mixed, single))
+        rs.append((f"gemm_nt.mixed[{name}] bitwise == single tile", 0.0 if same else 1.0, 0.0, bool(same)))
+    ref = a.float() @ b.float().t() + bi
+    rs.append(_res("gemm_nt.mixed[bias->bf16] vs torch", ops.gemm_nt(a, b, bias=bi), ref, 1e-2))
+    return rs
+
+
 def check_gemm_nt_gelu_bwd(dtype, M=200, N=384, K=256):
     a = _rnd(M, K, dtype=dtype, seed=5)
     b = _rnd(N, K, dtype=dtype, scale=0.1, seed=6)
@@ -475,6 +505,8 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=700, N=768, K=64, tile_m=16, out_f32=True))
             out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=16))
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
+        if dtype == torch.bfloat16:
+            out.append(check_gemm_nt_mixed_schedule)
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_nt_gelu_derivative_pair(d))
         if dtype == torch.bfloat16:

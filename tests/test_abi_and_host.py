@@ -51,6 +51,36 @@ def test_argument_validation_without_gpu():
     assert h.tav_gemm_tn_splits(512, 1536, 7999, 8, C.byref(cr), C.byref(ns)) == 0 and ns.value % 8 == 0
 
 
+def test_nt_schedule_mixes_tiles_only_when_the_last_round_is_short():
+    """tav_gemm_nt_schedule is host arithmetic: the video stack's N = 768 products at batch 32 (2.14 rounds of 256 x 256 tiles) take
+    two whole rounds of big tiles and hand the remaining rows to the 128-wide tile; batched, fp32 and forced-tile calls never split."""
+    h = _lib.lib()
+
+    def plan(M, N, K, in_dt=1, out_dt=1, nzb=1, hint=0, resid=False):
+        g = _lib.GemmNTArgs()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, K, K, N
+        g.in_dtype, g.out_dtype, g.nzb, g.nzg, g.tile_m_hint = in_dt, out_dt, nzb, 1, hint
+        if resid:
+            g.resid = 1                                  # only tested for NULL-ness by the planner
+        t, r, tr = C.c_int32(), C.c_int32(), C.c_int32()
+        assert h.tav_gemm_nt_schedule(C.byref(g), C.byref(t), C.byref(r), C.byref(tr)) == 0
+        return t.value, r.value, tr.value
+
+    M = 32 * 1464
+    t, r, tr = plan(M, 768, 768)
+    assert t == 16 and r == 170 * 256 and tr in (2, 3, 4)          # 510 big tiles = two rounds, 3328 rows left
+    assert plan(M, 768, 768, hint=17)[1:] == (M, 0)                # one tile for all rows on request
+    assert plan(M, 768, 768, hint=4) == (4, M, 0)
+    assert plan(M, 768, 768, in_dt=0, out_dt=0)[1:] == (M, 0)      # fp32 operands: 128-wide tiles only
+    assert plan(M, 768, 768, nzb=2)[1:] == (M, 0)                  # batched calls are never split
+    assert plan(4 * 128, 768, 768)[1:] == (4 * 128, 0)             # the text branch: under one round, nothing to split
+    t, r, tr = plan(256 * 256, 256, 768)                           # exactly one full round of big tiles: nothing left over
+    assert r == 256 * 256 and tr == 0
+    g = _lib.GemmNTArgs()
+    t_, r_, tr_ = C.c_int32(), C.c_int32(), C.c_int32()
+    assert h.tav_gemm_nt_schedule(C.byref(g), C.byref(t_), C.byref(r_), C.byref(tr_)) == -2     # M = 0: unsupported shape
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtavhip.so")

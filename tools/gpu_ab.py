@@ -94,7 +94,7 @@ if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/12
         a, b = rnd(M, K), rnd(N, K)
         bias = torch.randn(N, device=dev)
         row = []
-        for tm in (0, 2, 3, 4, 8, 16):
+        for tm in (0, 17, 2, 3, 4, 8, 16):      # 0 = library's plan (may mix tiles), 17 = its best single tile
             lo, _ = timeit(lambda: ops.gemm_nt(a, b, bias=bias, tile_m=tm), iters=30, reps=5)
             row.append(f"tm{tm} {lo:6.1f}")
         print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: " + "  ".join(row) + "  us")
