@@ -151,6 +151,13 @@ TAV_DEV unsigned lds_addr(const void* p) {
 // of a 64-bit multiply-add chain.  Issued from inline asm on purpose: hipcc would otherwise treat the DMA as a pending LDS write and
 // put `s_waitcnt vmcnt(0)` in front of every following ds_read, serialising load and compute.  The caller waits with a counted
 // vmcnt (wait_vmcnt0() in the simplest case) + a barrier before any wave reads the staged bytes.
+// A wave-uniform value the compiler computed on the VALU (integer division, ...) pinned to an SGPR.  __builtin_amdgcn_readfirstlane of a
+// value LLVM already knows to be uniform is folded away, and whether the dependent address chain then lives in SGPRs is a heuristic
+// (SIFixSGPRCopies) -- glds16_s needs its base there, so this one is opaque.
+// The hazard recognizer does not look inside inline asm, so the s_nops cover the gfx90a+ hazards by hand: "VALU writes VGPR -> readlane
+// reads it" (1 wait state; the v_mov that feeds %1 is often the instruction right in front) and "VALU writes SGPR -> VALU reads it
+// (2) / VMEM reads it (5)" behind.  Without them the lane read returns the register's PREVIOUS value.
+TAV_DEV int to_sgpr(int v) { int s; asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(v)); return s; }
 TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"

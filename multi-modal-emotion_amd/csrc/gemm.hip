@@ -58,7 +58,8 @@ TAV_DEV int xcd_remap(int id, int total) {
 //    (85 FLOP/B, one 8-wave workgroup per CU) is faster wherever its coarser tile grid still fills the chip;
 //  * the tile count must divide well over the 256 CUs (M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle in
 //    the last round, 732 tiles of 96 rows do not) and small-M problems must still produce enough workgroups.
-template <typename T, typename TO, int TM, int NST, int NW, int TNW>
+enum { NT_GEN = 0, NT_PLAIN = 1, NT_RESID = 2, NT_GELU_D = 3, NT_MUL_D = 4 };   // epilogue flavours (see the epilogue)
+template <typename T, typename TO, int TM, int NST, int NW, int TNW, int EPI = NT_GEN>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
     constexpr int ES = ET<T>::ES;
     constexpr bool F8 = std::is_same<T, fp8>::value;      // e4m3 operands: 128 k-values per 128-byte K-tile, one block-scaled MFMA per 16x16 tile
@@ -82,9 +83,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const int first_m = (tile / gsz) * GROUP_M;
     const int gm = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
     const int rem = tile % gsz;
-    const int tm_idx = first_m + rem % gm, tn_idx = rem / gm;
+    // (uniform integer divisions run on the VALU; to_sgpr pins their results -- and every address derived from them -- back to SGPRs)
+    const int tm_idx = to_sgpr(first_m + rem % gm), tn_idx = to_sgpr(rem / gm);
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-    const int z = blockIdx.y, zb = z / p.nzg, zg = z - zb * p.nzg;
+    const int z = blockIdx.y, zb = to_sgpr(z / p.nzg), zg = z - zb * p.nzg;
 
     const char* Ab = p.A + (zb * p.a_zb + zg * p.a_zg) * ES;
     const char* Bb = p.B + (zb * p.b_zb + zg * p.b_zg) * ES;
@@ -202,6 +204,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     // uncoalesced residual reads.  Instead the f32 accumulator tile goes through the (now idle) staging LDS -- one ds_write_b128
     // per 16x16 tile, 16-B chunks XOR-swizzled with the row so both the writes and the row-major reads are conflict free -- and
     // the epilogue runs row-major: 32 threads per row, 16 B per thread, every global access a full 512-B (f32) / 256-B (bf16) run.
+#ifdef TAV_ABL_NOEPI                                        // timing ablation: prologue + main loop only
+    if (p.alpha != 12345.f) { if (acc[0][0][0] == 1.2345e-30f) p.C[0] = 1; return; }
+#endif
     __syncthreads();                                       // all waves finished reading the operand images
     float* sC = reinterpret_cast<float*>(smem);            // [EP_ROWS][BN] f32 inside the (now idle) staging buffers
     constexpr int ROWB_C = BN * 4;                          // bytes per staged row
@@ -216,6 +221,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const TS* Gin = p.gelu_in ? reinterpret_cast<const TS*>(p.gelu_in) + coff : nullptr;
     const float alpha = p.alpha * (p.sa ? *p.sa : 1.f) * (p.sb ? *p.sb : 1.f);
     const float* R = p.resid ? p.resid + coff : nullptr;
+    // What the epilogue does is a launch-time constant.  EPI = NT_GEN reads it from the arguments (any combination); the four flavours the
+    // transformer layers use are compiled as straight-line code (the generic loop spends more issue slots on uniform branches than on the
+    // data: with two waves per SIMD and the matrix pipe idle, the epilogue of a 256 x 256 tile is VALU-issue bound).
+    constexpr bool GEN = EPI == NT_GEN;
+    const bool f_resid = GEN ? (R != nullptr) : (EPI == NT_RESID);                    // + f32 residual
+    const bool f_pre = GEN ? (Cpre != nullptr && !(p.act & 2)) : false;                // second output: the pre-activation
+    const bool f_act3 = GEN ? ((p.act & 3) == 3) : (EPI == NT_GELU_D);                 // GELU out, gelu' to the second output
+    const bool f_gelu = GEN ? ((p.act & 3) == 1) : false;                              // GELU out only
+    const bool f_gin = GEN ? (Gin != nullptr) : (EPI == NT_MUL_D);                     // multiply by gelu'(side input)
+    const bool f_gin_d = GEN ? ((p.act & 4) != 0) : true;                              // ... which already is the derivative
+    const bool f_acc = GEN ? (p.accumulate != 0) : false;
     const int ch = tid % CPR, rr = tid / CPR;              // this thread's 16-B column chunk (fixed) and row within an iteration
     constexpr int RPI = 64 * NW / CPR;                      // rows per iteration of the store loop
     const int n = n0 + 4 * ch;
@@ -223,37 +239,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     if (n < p.N && p.bias) bv = ld4(p.bias + zg * p.bias_zg + n);
     constexpr int NIT = EP_ROWS / RPI;                      // rows per thread and pass (<= 16)
     static_assert(EP_ROWS % RPI == 0 && NIT <= 16, "epilogue rows per thread");
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int row_lo = pass * EP_ROWS;
-        if (pass) __syncthreads();                          // the previous pass has been stored
-        // Side inputs of this pass (f32 residual, pre-activation for gelu', or C itself when accumulating) are requested BEFORE the
-        // accumulators are staged: their HBM/L2 latency then runs under the LDS writes and the barrier instead of in front of every
-        // store (the fragment registers of the main loop are dead by now).  One flavour per launch; the rare combinations fall back
-        // to loading inside the store loop.
-        constexpr int PD = TNW == 8 ? 8 : NIT;              // requests in flight per thread (the 256 x 256 tile has 128 accumulator registers live)
-        f32x4 side[PD];                                     // (gelu_in: two packed words in .x/.y)
-        const bool pre_r = R != nullptr, pre_g = !pre_r && Gin != nullptr && sizeof(TS) == 2, pre_c = !pre_r && !pre_g && p.accumulate;
-        auto side_load = [&](int it) -> f32x4 {
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N; // no bounds checks inside (all but the last row / column of tiles)
+    // Side inputs of a pass (f32 residual, gelu' for the dgrad, or C itself when accumulating) are requested BEFORE the accumulators are
+    // staged: their HBM/L2 latency then runs under the LDS writes and the barrier instead of in front of every store (the fragment
+    // registers of the main loop are dead by now).  One flavour per launch; the rare combinations load inside the store loop.
+#ifdef TAV_PD_OLD
+    constexpr int PD = TNW == 8 ? 8 : NIT;
+#else
+    constexpr int PD = NIT > 8 ? 8 : NIT;
+#endif
+    // ^                   // requests in flight per thread (16 x 4 registers on top of the accumulators would spill)
+    constexpr bool EARLY = (TNW == 4);                      // ... and no registers to spare while they are
+    const bool pre_r = f_resid, pre_g = !pre_r && f_gin && sizeof(TS) == 2, pre_c = !pre_r && !pre_g && f_acc && sizeof(TO) == 4;
+    const bool any_side = pre_r || pre_c || pre_g;
+    // Addresses: a wave-uniform 64-bit base (the tile's first row, SGPRs) + a 32-bit per-thread BYTE offset that advances by a uniform
+    // step per row iteration: the global_load/store "saddr + voffset" form, one v_add per access.  (long)m * ld + n per access costs two
+    // quarter-rate 32-bit multiplies and a 64-bit multiply-add per address, which made the address arithmetic the largest part of the
+    // loop.  The host checks that a tile's offsets fit 32 bits.
+    char* const Cb = reinterpret_cast<char*>(C + (long)m0 * p.ldc);
+    char* const Pb = Cpre ? reinterpret_cast<char*>(Cpre + (long)m0 * p.ld_pre) : nullptr;
+    const char* const Gb = Gin ? reinterpret_cast<const char*>(Gin + (long)m0 * p.ld_gelu) : nullptr;
+    const char* const Rb = R ? reinterpret_cast<const char*>(R + (long)m0 * p.ld_resid) : nullptr;
+    const unsigned s_c = RPI * (unsigned)p.ldc * sizeof(TO), s_p = RPI * (unsigned)p.ld_pre * sizeof(TO);
+    const unsigned s_g = RPI * (unsigned)p.ld_gelu * sizeof(TS), s_r = RPI * (unsigned)p.ld_resid * 4u;
+    auto run_pass = [&](int row_lo, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const unsigned row = (unsigned)(row_lo + rr);        // (offsets depend on the pass: nothing for the compiler to hoist and keep live)
+        const unsigned o_c = (row * (unsigned)p.ldc + (unsigned)n) * (unsigned)sizeof(TO), o_p = (row * (unsigned)p.ld_pre + (unsigned)n) * (unsigned)sizeof(TO);
+        const unsigned o_g = (row * (unsigned)p.ld_gelu + (unsigned)n) * (unsigned)sizeof(TS), o_r = (row * (unsigned)p.ld_resid + (unsigned)n) * 4u;
+        f32x4 side[PD];                                     // (gelu' side input: two packed words in .x/.y)
+        auto side_load = [&](int it) __attribute__((always_inline)) -> f32x4 {
             const int m = m0 + row_lo + rr + it * RPI;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N && m < p.M) {
-                if (pre_r) v = ld4(R + (long)m * p.ld_resid + n);
-                else if (pre_c) { if constexpr (sizeof(TO) == 4) v = ld4(reinterpret_cast<const float*>(C) + (long)m * p.ldc + n); }
+#ifdef TAV_ABL_NOSIDE
+            if (p.alpha == 12345.f)
+#endif
+            if (FULL || (n < p.N && m < p.M)) {
+                if (pre_r) v = ld4(reinterpret_cast<const float*>(Rb + (o_r + it * s_r)));
+                else if (pre_c) { if constexpr (sizeof(TO) == 4) v = ld4(reinterpret_cast<const float*>(Cb + (o_c + it * s_c))); }
                 else if (pre_g) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(Gin) + ((long)m * p.ld_gelu + n) * 2);
+                    const uint2 w = *reinterpret_cast<const uint2*>(Gb + (o_g + it * s_g));
                     v[0] = __uint_as_float(w.x);
                     v[1] = __uint_as_float(w.y);
                 }
             }
             return v;
         };
-        auto side_loads = [&]() {
-            if (!(pre_r || pre_c || pre_g)) return;
+        auto side_loads = [&]() __attribute__((always_inline)) {
+            if (!any_side) return;
 #pragma unroll
             for (int it = 0; it < PD; ++it) side[it] = side_load(it);
         };
-        constexpr bool EARLY = (TNW == 4);                  // the 256 x 256 tile has no registers to spare while its accumulators are live
         if constexpr (EARLY) side_loads();
         if (wm * 16 * TM >= row_lo && wm * 16 * TM < row_lo + EP_ROWS) {
 #pragma unroll
@@ -266,43 +302,80 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 }
             }
         }
-        if constexpr (!EARLY) side_loads();                 // staged accumulators are dead: all 16 requests fly across the barrier
+        if constexpr (!EARLY) side_loads();                 // staged accumulators are dead: the requests fly across the barrier
         __syncthreads();
-        if (n < p.N) {
+        if (FULL || n < p.N) {
+            auto staged = [&](int it) __attribute__((always_inline)) -> f32x4 {
+                const int r = rr + it * RPI;
+                return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
+            };
+            f32x4 v_next = staged(0);                           // the staged row is read one iteration ahead of its use
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int r = rr + it * RPI;
                 const int m = m0 + row_lo + r;
                 const f32x4 sv = side[it % PD];
-                if constexpr (PD < NIT) { if (it + PD < NIT && (pre_r || pre_c || pre_g)) side[it % PD] = side_load(it + PD); }
-                if (m < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sC) + r * ROWB_C + ((ch ^ (r & 31)) << 4));
+                if constexpr (PD < NIT) { if (it + PD < NIT && any_side) side[it % PD] = side_load(it + PD); }
+                f32x4 v = v_next;
+                if (it + 1 < NIT) v_next = staged(it + 1);
+                if (FULL || m < p.M) {
                     v = v * alpha + bv;
-                    if (Cpre && !(p.act & 2)) st4(Cpre + (long)m * p.ld_pre + n, v);
-                    if ((p.act & 3) == 3) {                     // GELU out, gelu' to C_pre
+#ifdef TAV_ABL_NOSTORE
+                    if (p.alpha == 12345.f)
+#endif
+                    if (f_pre) st4(reinterpret_cast<TO*>(Pb + (o_p + it * s_p)), v);
+                    if (f_act3) {                               // GELU out, gelu' to C_pre
                         f32x4 d;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<TS>(v[e], y, dy); v[e] = y; d[e] = dy; }
-                        if (Cpre) st4(Cpre + (long)m * p.ld_pre + n, d);
-                    } else if (p.act & 1) { v[0] = gelu_t<TS>(v[0]); v[1] = gelu_t<TS>(v[1]); v[2] = gelu_t<TS>(v[2]); v[3] = gelu_t<TS>(v[3]); }
-                    if (Gin) {
+#ifdef TAV_ABL_NOSTORE
+                        if (p.alpha == 12345.f)
+#endif
+                        if (GEN ? Cpre != nullptr : true) st4(reinterpret_cast<TO*>(Pb + (o_p + it * s_p)), d);
+                    } else if (f_gelu) { v[0] = gelu_t<TS>(v[0]); v[1] = gelu_t<TS>(v[1]); v[2] = gelu_t<TS>(v[2]); v[3] = gelu_t<TS>(v[3]); }
+                    if (f_gin) {
                         f32x4 u;
                         if (pre_g) {
                             const uint32_t w0 = __float_as_uint(sv[0]), w1 = __float_as_uint(sv[1]);
                             u = f32x4{bf16_bits_to_f32(w0 & 0xffffu), bf16_bits_to_f32(w0 >> 16), bf16_bits_to_f32(w1 & 0xffffu), bf16_bits_to_f32(w1 >> 16)};
                         }
-                        else u = ld4(Gin + (long)m * p.ld_gelu + n);
-                        if (p.act & 4) v *= u;                  // the side input already is gelu'(pre-activation)
+                        else u = ld4(reinterpret_cast<const TS*>(Gb + (o_g + it * s_g)));
+                        if (f_gin_d) v *= u;                    // the side input already is gelu'(pre-activation)
                         else { v[0] *= gelu_grad_t<TS>(u[0]); v[1] *= gelu_grad_t<TS>(u[1]); v[2] *= gelu_grad_t<TS>(u[2]); v[3] *= gelu_grad_t<TS>(u[3]); }
                     }
                     if (pre_r) v += sv;
-                    else if (R) v += ld4(R + (long)m * p.ld_resid + n);
-                    if (p.accumulate) {
-                        if (pre_c && sizeof(TO) == 4) v += sv;
-                        else v += ld4(C + (long)m * p.ldc + n);
+                    if (f_acc) {
+                        if (pre_c) v += sv;
+                        else v += ld4(reinterpret_cast<const TO*>(Cb + (o_c + it * s_c)));
                     }
-                    st4(C + (long)m * p.ldc + n, v);
+#ifdef TAV_ABL_NOSTORE                                      // timing ablation: everything but the output stores (never true at run time)
+                    if (p.alpha == 12345.f)
+#endif
+                    st4(reinterpret_cast<TO*>(Cb + (o_c + it * s_c)), v);
                 }
+            }
+        }
+    };
+    if constexpr (GEN) {
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {          // (one copy: the generic epilogue is large enough)
+            if (pass) __syncthreads();                      // the previous pass has been stored
+            run_pass(pass * EP_ROWS, std::false_type{});
+        }
+    } else {
+        // passes unrolled: inside a loop the waitcnt pass merges the pending-load state at the header and protects the first reuse of a
+        // side register with s_waitcnt vmcnt(0) -- which also waits for every STORE of the previous pass to be acknowledged
+        if (interior) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (pass) __syncthreads();
+                run_pass(pass * EP_ROWS, std::true_type{});
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (pass) __syncthreads();
+                run_pass(pass * EP_ROWS, std::false_type{});
             }
         }
     }
@@ -662,6 +735,10 @@ static int nt_validate(const tav_gemm_nt_args* a, bool need_ptrs) {
     if ((a->K * es) % 128 != 0) return TAV_ERR_SHAPE;      // K-tile = 128 bytes
     if ((a->M * a->lda + a->K) * es >= (1ll << 32) || (a->N * a->ldb + a->K) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets per (zb, zg) slice
     if (a->N % 4 != 0) return TAV_ERR_SHAPE;
+    {   // the epilogue addresses a tile's rows with 32-bit element offsets from the tile's first row
+        const int64_t ldmax = std::max(std::max(a->ldc, a->C_pre ? a->ld_pre : 0), std::max(a->gelu_in ? a->ld_gelu_in : 0, a->resid ? a->ld_resid : 0));
+        if (ldmax < 0 || 256 * ldmax + a->N >= (1ll << 30)) return TAV_ERR_SHAPE;
+    }
     const int pk = 16 / es;
     if (a->lda % pk || a->ldb % pk || a->ldc % 4) return TAV_ERR_ALIGN;
     if (a->a_zb % pk || a->a_zg % pk || a->b_zb % pk || a->b_zg % pk || a->c_zb % 4 || a->c_zg % 4) return TAV_ERR_ALIGN;
@@ -728,19 +805,19 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         if (in_dtype != TAV_BF16) nst = 2;
         dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
         const size_t lds = (size_t)nst * (bm + bn) * 128;    // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
-#define TAV_NT_LAUNCH_S(TT, TOO, NS)                                                                                 \
-    do {                                                                                                             \
-        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4, 4>), grid, block, lds, stream, p);         \
-        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, NS, 4, 4>), grid, block, lds, stream, p);    \
-        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, NS, 4, 4>), grid, block, lds, stream, p);                 \
+#define TAV_NT_LAUNCH_S(TT, TOO, NS, EP)                                                                                 \
+    do {                                                                                                                 \
+        if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4, 4, EP>), grid, block, lds, stream, p);         \
+        else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 3, NS, 4, 4, EP>), grid, block, lds, stream, p);    \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 2, NS, 4, 4, EP>), grid, block, lds, stream, p);                 \
     } while (0)
-#define TAV_NT_LAUNCH(TT, TOO)                                                                                       \
-    do {                                                                                                             \
-        if (tm == 16) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 2, 8, 8>), grid, block, lds, stream, p);         \
-        else if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8, 4>), grid, block, lds, stream, p);     \
-        else if (nst == 4) TAV_NT_LAUNCH_S(TT, TOO, 4);                                                               \
-        else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3);                                                               \
-        else TAV_NT_LAUNCH_S(TT, TOO, 2);                                                                             \
+#define TAV_NT_LAUNCH(TT, TOO, EP)                                                                                       \
+    do {                                                                                                                 \
+        if (tm == 16) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 2, 8, 8, EP>), grid, block, lds, stream, p);         \
+        else if (tm == 8) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, 3, 8, 4, NT_GEN>), grid, block, lds, stream, p); \
+        else if (nst == 4) TAV_NT_LAUNCH_S(TT, TOO, 4, EP);                                                               \
+        else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3, NT_GEN);                                                           \
+        else TAV_NT_LAUNCH_S(TT, TOO, 2, EP);                                                                             \
     } while (0)
         if (in_dtype == TAV_FP8) {
             if (tm == 16) {
@@ -751,8 +828,26 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
                 else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
             }
         } else if (in_dtype == TAV_BF16) {
-            if (out_dtype == TAV_BF16) TAV_NT_LAUNCH(bf16, bf16);
-            else TAV_NT_LAUNCH(bf16, float);
+            // the epilogue flavours of the transformer layers as straight-line code; everything else takes the generic epilogue
+            const bool side = p.resid || p.Cpre || p.gelu_in || p.accumulate;
+            int epi = NT_GEN;
+            if (!side && p.act == 0) epi = NT_PLAIN;
+            else if (p.resid && !p.Cpre && !p.gelu_in && !p.accumulate && p.act == 0 && out_dtype == TAV_F32) epi = NT_RESID;
+            else if (p.Cpre && (p.act & 3) == 3 && !p.resid && !p.gelu_in && !p.accumulate && out_dtype == TAV_BF16) epi = NT_GELU_D;
+            else if (p.gelu_in && (p.act & 4) && !(p.act & 3) && !p.resid && !p.Cpre && !p.accumulate && out_dtype == TAV_BF16) epi = NT_MUL_D;
+#ifdef TAV_ABL_GENEPI
+            epi = NT_GEN;
+#endif
+            if (out_dtype == TAV_BF16) {
+                if (epi == NT_PLAIN) TAV_NT_LAUNCH(bf16, bf16, NT_PLAIN);
+                else if (epi == NT_GELU_D) TAV_NT_LAUNCH(bf16, bf16, NT_GELU_D);
+                else if (epi == NT_MUL_D) TAV_NT_LAUNCH(bf16, bf16, NT_MUL_D);
+                else TAV_NT_LAUNCH(bf16, bf16, NT_GEN);
+            } else {
+                if (epi == NT_PLAIN) TAV_NT_LAUNCH(bf16, float, NT_PLAIN);
+                else if (epi == NT_RESID) TAV_NT_LAUNCH(bf16, float, NT_RESID);
+                else TAV_NT_LAUNCH(bf16, float, NT_GEN);
+            }
         } else {
             if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
             else if (tm == 3) hipLaunchKernelGGL((gemm_nt_kernel<float, float, 3, 2, 4, 4>), grid, block, lds, stream, p);
