@@ -237,4 +237,33 @@ template <> TAV_DEV void gelu_both_t<bf16>(float x, float& y, float& dy) {
     dy = fmaf(x * 0.39894228040143267794f, e, c);
 }
 
+// The same pair for four values at once, written on two-wide vectors so the arithmetic compiles to packed FP32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes of work per issue slot); rcp and exp2 stay scalar.  Same formula and constants as
+// gelu_parts_fast -- the FFN1 epilogue of a 256 x 256 tile is VALU bound on exactly this.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+TAV_DEV void gelu_both2_fast(f32x2 x, f32x2& y, f32x2& dy) {
+    const f32x2 z = f32x2{fabsf(x[0]), fabsf(x[1])} * 0.70710678118654752440f;
+    const f32x2 den = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 zz = z * z * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};                  // exp(-x^2/2)
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 erf_abs = 1.0f - poly * e;
+    const f32x2 cdf = f32x2{copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])} * 0.5f + 0.5f;
+    y = x * cdf;
+    dy = (x * 0.39894228040143267794f) * e + cdf;
+}
+template <typename T> TAV_DEV void gelu_both4_t(f32x4 x, f32x4& y, f32x4& dy);
+template <> TAV_DEV void gelu_both4_t<float>(f32x4 x, f32x4& y, f32x4& dy) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float a, b; gelu_both_t<float>(x[e], a, b); y[e] = a; dy[e] = b; }
+}
+template <> TAV_DEV void gelu_both4_t<bf16>(f32x4 x, f32x4& y, f32x4& dy) {
+    f32x2 y0, d0, y1, d1;
+    gelu_both2_fast(f32x2{x[0], x[1]}, y0, d0);
+    gelu_both2_fast(f32x2{x[2], x[3]}, y1, d1);
+    y = f32x4{y0[0], y0[1], y1[0], y1[1]};
+    dy = f32x4{d0[0], d0[1], d1[0], d1[1]};
+}
+
 }  // namespace tav

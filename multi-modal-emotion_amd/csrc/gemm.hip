@@ -90,7 +90,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 
     const char* Ab = p.A + (zb * p.a_zb + zg * p.a_zg) * ES;
     const char* Bb = p.B + (zb * p.b_zb + zg * p.b_zg) * ES;
-
     // LDS-DMA staging (global_load_lds_dwordx4): one wave instruction fills 64 consecutive 16-B slots = 8 rows x 8 chunk
     // slots of the image; the LDS side is linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE
     // chunk each lane fetches.  Wave w stages rows [8*TM*w, +8*TM) of A and [8*PB*w, +8*PB) of B.
@@ -243,12 +242,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     // Side inputs of a pass (f32 residual, gelu' for the dgrad, or C itself when accumulating) are requested BEFORE the accumulators are
     // staged: their HBM/L2 latency then runs under the LDS writes and the barrier instead of in front of every store (the fragment
     // registers of the main loop are dead by now).  One flavour per launch; the rare combinations load inside the store loop.
+    // Requests in flight per thread.  vmcnt retires in issue order, so with a rolling prefetch every wait for a side value also waits for
+    // the STORES issued before it (their write acknowledgements), and the loop runs at "depth" accesses per memory round trip.  The gelu'
+    // side input takes two registers per row: all of a pass's rows are requested up front, every load is older than every store and the
+    // loop never waits on a store.  The f32 residual takes four (16 x 4 registers on top of the accumulators would spill): depth 8.
 #ifdef TAV_PD_OLD
-    constexpr int PD = TNW == 8 ? 8 : NIT;
-#else
     constexpr int PD = NIT > 8 ? 8 : NIT;
+#else
+    constexpr int PD = (EPI == NT_MUL_D) ? NIT : (NIT > 8 ? 8 : NIT);
 #endif
-    // ^                   // requests in flight per thread (16 x 4 registers on top of the accumulators would spill)
     constexpr bool EARLY = (TNW == 4);                      // ... and no registers to spare while they are
     const bool pre_r = f_resid, pre_g = !pre_r && f_gin && sizeof(TS) == 2, pre_c = !pre_r && !pre_g && f_acc && sizeof(TO) == 4;
     const bool any_side = pre_r || pre_c || pre_g;
@@ -325,9 +327,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 #endif
                     if (f_pre) st4(reinterpret_cast<TO*>(Pb + (o_p + it * s_p)), v);
                     if (f_act3) {                               // GELU out, gelu' to C_pre
-                        f32x4 d;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<TS>(v[e], y, dy); v[e] = y; d[e] = dy; }
+                        f32x4 d, y4;
+#ifdef TAV_ABL_SCALARGELU
+                        for (int e = 0; e < 4; ++e) { float y, dy; gelu_both_t<TS>(v[e], y, dy); y4[e] = y; d[e] = dy; }
+#else
+                        gelu_both4_t<TS>(v, y4, d);
+#endif
+                        v = y4;
 #ifdef TAV_ABL_NOSTORE
                         if (p.alpha == 12345.f)
 #endif

@@ -64,20 +64,25 @@ if "layer" in what:       # the eight NT GEMMs of ONE video-encoder layer (forwa
     b3, b1, bf = torch.randn(3 * H, device=dev), torch.randn(H, device=dev), torch.randn(F, device=dev)
     res = torch.randn(M, H, device=dev)
     h_lp, u_lp, dqkv = rnd(M, F), rnd(M, F), rnd(M, 3 * H)
-    tmh = int(os.environ.get("TAV_TM", "0"))
+    soff = int(os.environ.get("TAV_SIDE_OFF", "0"))       # experiment: shift the gelu' side tensor against the output tensor (elements)
+    if soff:
+        u_lp = rnd(M * F + soff)[soff:].view(M, F)
+    tmh = int(os.environ.get("TAV_TM", "0"))          # + 256: stagger experiment
     cases = [("qkv      bias            -> bf16", lambda: ops.gemm_nt(x_lp, w_qkv, bias=b3, tile_m=tmh), 2 * M * 3 * H * H),
              ("out-proj bias+resid      -> f32 ", lambda: ops.gemm_nt(x_lp, w_o, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * H),
              ("ffn1     bias+gelu+pre   -> bf16", lambda: ops.gemm_nt(x_lp, w_1, bias=bf, act=1, want_pre=True, tile_m=tmh), 2 * M * F * H),
              ("ffn2     bias+resid      -> f32 ", lambda: ops.gemm_nt(h_lp, w_2, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
-             ("d ffn2   * gelu'(u)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, gelu_in=u_lp, tile_m=tmh), 2 * M * F * H),
+             ("d ffn2   * gelu'(u)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, gelu_in=u_lp, act=4, tile_m=tmh), 2 * M * F * H),
+             ("(same shape, plain)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, tile_m=tmh), 0),
              ("d ffn1                   -> f32 ", lambda: ops.gemm_nt(h_lp, w_1_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
              ("d out-proj               -> bf16", lambda: ops.gemm_nt(x_lp, w_o_t, tile_m=tmh), 2 * M * H * H),
              ("d qkv                    -> f32 ", lambda: ops.gemm_nt(dqkv, w_qkv_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * 3 * H)]
     tot_t = tot_f = 0.0
     for name, fn, fl in cases:
         lo, med = timeit(fn, iters=20, reps=5)
-        tot_t += lo
-        tot_f += fl
+        if fl:
+            tot_t += lo
+            tot_f += fl
         print(f"[{tag}] layer-NT {name}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
     print(f"[{tag}] layer-NT total (b={B}, tile hint {tmh}): {tot_t:8.1f} us  {tot_f / tot_t / 1e6:7.1f} TF")
 if "tn" in what:
