@@ -673,8 +673,6 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 using namespace tav;
 
 // tile height: minimise (tiles per CU, rounded up) x (cost of one tile ~ TM + fixed overhead)
-// `epi`: what the epilogue moves and computes besides the plain store -- bit 0: f32 residual (or accumulate) read, bit 1: f32 output,
-// bit 2: GELU (+ second output) or gelu'(side input).
 static int nt_small_tile(int M, int N, int nz) {
     const int tiles_n = (N + 127) / 128;
     int tm = 4;
@@ -686,17 +684,21 @@ static int nt_small_tile(int M, int N, int nz) {
     }
     return tm;
 }
-// Fitted launch times in microseconds: rounds x (K-tiles x time per K-tile + prologue and epilogue), constants from tools/gpu_ab.py `tiles`
-// and `layer` at batch 32 (they reproduce its timings within ~5 %).
+// Fitted launch times in microseconds: rounds x (K-tiles x time per K-tile + prologue and epilogue), constants from tools/gpu_ab.py `layer`
+// at batch 32 and 8 with per-tile hints (profiles/r02_microbench_*; they reproduce its timings within ~5 %).  K-tiles beyond the 36th cost
+// 1.3-1.6x (K = 3072 operands; not a channel-aliasing effect -- padding the row stride changes nothing).
+// `epi`: bit 0 f32 residual / accumulate read, bit 1 f32 output, bit 2 GELU, bit 3 gelu' side input, bit 4 second output.
 static double nt_small_us(int M, int N, double nk, int nz, int tm, int epi) {
-    static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.56, 0.72, 0.85}, fix[5] = {0, 0, 4.2, 4.9, 5.6};
+    static const double slots[5] = {0, 0, 768, 512, 512}, tk[5] = {0, 0, 0.56, 0.72, 0.85}, fix[5] = {0, 0, 3.6, 4.0, 4.4};
     const long t = (long)((M + 32 * tm - 1) / (32 * tm)) * ((N + 127) / 128) * nz;
     // two workgroups per CU hide one's epilogue behind the other's main loop: the residual read costs little after a short K loop
-    const double e = ((epi & 1) ? 2.0 + 0.2 * nk : 0.0) + ((epi & 2) ? 2.0 : 0.0) + ((epi & 4) ? 4.5 : 0.0);
-    return (double)((long)((t + slots[tm] - 1) / slots[tm])) * (nk * tk[tm] + fix[tm] + e * tm / 4.0);
+    const double e = ((epi & 1) ? 2.0 + 0.2 * nk : 0.0) + ((epi & 2) ? 2.0 : 0.0) + ((epi & 4) ? 2.0 : 0.0) + ((epi & 8) ? 1.0 : 0.0) + ((epi & 16) ? 2.5 : 0.0);
+    const double kt = (nk <= 36.0 ? nk : 36.0 + 1.6 * (nk - 36.0)) * tk[tm];
+    return (double)((long)((t + slots[tm] - 1) / slots[tm])) * (kt + fix[tm] + e * tm / 4.0);
 }
 static double nt_big_round_us(double nk, int epi) {
-    return nk * 1.48 + 9.4 + ((epi & 1) ? 18.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 10.0 : 0.0);
+    const double kt = (nk <= 36.0 ? nk : 36.0 + 1.33 * (nk - 36.0)) * 1.48;
+    return kt + 6.5 + ((epi & 1) ? 9.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 3.0 : 0.0) + ((epi & 8) ? 4.7 : 0.0) + ((epi & 16) ? 6.7 : 0.0);
 }
 // Returns the tile for the launch; when `rows_big` is given and a mixed schedule is faster, *rows_big < M is the number of leading rows that
 // take the 256 x 256 tile (whole rounds of 256 workgroups) and *tm_rest the 128-wide tile of a second launch over the remaining rows.
@@ -724,7 +726,7 @@ static int nt_pick_tile(int M, int N, int K, int nz, bool bf16_in, int epi, int*
             if (m_tiles >= 1 && m_rest > 0) {
                 const int tr = nt_small_tile(m_rest, N, 1);
                 const double us_split = (double)((m_tiles * tn_big + 255) / 256) * big_round + nt_small_us(m_rest, N, nk, 1, tr, epi) + 2.0;   // + the seam between two launches
-                if (us_split < 0.97 * us_best) { tm = 16; *rows_big = rows_a; *tm_rest = tr; }
+                if (us_split < 0.93 * us_best) { tm = 16; *rows_big = rows_a; *tm_rest = tr; }   // (the model is good to ~5 %: only clear wins)
             }
         }
     }
@@ -764,7 +766,7 @@ static void nt_plan(const tav_gemm_nt_args* a, int* tm_out, int* rows_big, int* 
     if (a->in_dtype == TAV_F32 && (tm == 8 || tm == 16)) tm = 4;
     if (tm != 8 && tm != 16 && (tm < 2 || tm > 4))
         tm = nt_pick_tile((int)a->M, (int)a->N, (int)(a->K * es / 2), nz, a->in_dtype != TAV_F32,
-                          ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act || a->gelu_in) ? 4 : 0),
+                          ((a->resid || a->accumulate) ? 1 : 0) | (a->out_dtype == TAV_F32 ? 2 : 0) | ((a->act & 3) ? 4 : 0) | (a->gelu_in ? 8 : 0) | (a->C_pre ? 16 : 0),
                           may_split ? rows_big : nullptr, tm_rest);
     if (a->in_dtype == TAV_FP8 && tm != 16) tm = 4;          // fp8 operands: the 128 x 128 and 256 x 256 tiles only
     *tm_out = tm;

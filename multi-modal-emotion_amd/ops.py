@@ -60,7 +60,7 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
         out = torch.empty(out_shape or (M, N), dtype=out_dtype, device=a.device)
     if ldc is None:
         ldc = out.stride(-2)
-    pre = torch.empty_like(out) if want_pre else None
+    pre = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device) if want_pre else None   # (same row stride as out: ld_pre = ldc)
     g = L.GemmNTArgs()
     g.A, g.B, g.C, g.C_pre = ptr(a), ptr(b), ptr(out), ptr(pre)
     g.bias, g.gelu_in, g.resid = ptr(bias), ptr(gelu_in), ptr(resid)

@@ -63,17 +63,20 @@ if "layer" in what:       # the eight NT GEMMs of ONE video-encoder layer (forwa
     w_qkv_t, w_o_t, w_1_t, w_2_t = rnd(H, 3 * H), rnd(H, H), rnd(H, F), rnd(F, H)
     b3, b1, bf = torch.randn(3 * H, device=dev), torch.randn(H, device=dev), torch.randn(F, device=dev)
     res = torch.randn(M, H, device=dev)
-    h_lp, u_lp, dqkv = rnd(M, F), rnd(M, F), rnd(M, 3 * H)
-    soff = int(os.environ.get("TAV_SIDE_OFF", "0"))       # experiment: shift the gelu' side tensor against the output tensor (elements)
-    if soff:
-        u_lp = rnd(M * F + soff)[soff:].view(M, F)
-    tmh = int(os.environ.get("TAV_TM", "0"))          # + 256: stagger experiment
-    cases = [("qkv      bias            -> bf16", lambda: ops.gemm_nt(x_lp, w_qkv, bias=b3, tile_m=tmh), 2 * M * 3 * H * H),
+    pad = int(os.environ.get("TAV_PAD", "0"))             # experiment: row stride of the wide [M, 3072] / [M, 2304] activations = width + pad elements
+
+    def wide(n, dtype=torch.bfloat16):
+        return rnd(M, n + pad, dtype=dtype)[:, :n] if pad else rnd(M, n, dtype=dtype)
+
+    h_lp, u_lp, dqkv = wide(F), wide(F), wide(3 * H)
+    o_qkv, o_h, o_du = wide(3 * H), wide(F), wide(F)
+    tmh = int(os.environ.get("TAV_TM", "0"))
+    cases = [("qkv      bias            -> bf16", lambda: ops.gemm_nt(x_lp, w_qkv, bias=b3, out=o_qkv, tile_m=tmh), 2 * M * 3 * H * H),
              ("out-proj bias+resid      -> f32 ", lambda: ops.gemm_nt(x_lp, w_o, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * H),
-             ("ffn1     bias+gelu+pre   -> bf16", lambda: ops.gemm_nt(x_lp, w_1, bias=bf, act=1, want_pre=True, tile_m=tmh), 2 * M * F * H),
+             ("ffn1     bias+gelu+gelu' -> bf16", lambda: ops.gemm_nt(x_lp, w_1, bias=bf, act=3, want_pre=True, out=o_h, tile_m=tmh), 2 * M * F * H),
              ("ffn2     bias+resid      -> f32 ", lambda: ops.gemm_nt(h_lp, w_2, bias=b1, resid=res, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
-             ("d ffn2   * gelu'(u)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, gelu_in=u_lp, act=4, tile_m=tmh), 2 * M * F * H),
-             ("(same shape, plain)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, tile_m=tmh), 0),
+             ("d ffn2   * gelu'         -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, gelu_in=u_lp, act=4, out=o_du, tile_m=tmh), 2 * M * F * H),
+             ("(same shape, plain)      -> bf16", lambda: ops.gemm_nt(x_lp, w_2_t, out=o_du, tile_m=tmh), 0),
              ("d ffn1                   -> f32 ", lambda: ops.gemm_nt(h_lp, w_1_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * F),
              ("d out-proj               -> bf16", lambda: ops.gemm_nt(x_lp, w_o_t, tile_m=tmh), 2 * M * H * H),
              ("d qkv                    -> f32 ", lambda: ops.gemm_nt(dqkv, w_qkv_t, out_dtype=torch.float32, tile_m=tmh), 2 * M * H * 3 * H)]
