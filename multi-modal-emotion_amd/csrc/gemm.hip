@@ -434,18 +434,32 @@ template <> TAV_DEV uint4 tn_frag<float>(const char* tile, int krow0, int col0, 
     return r;
 }
 
+// K-tile and ring depth per dtype (64 tokens, two buffers).  A deeper ring of shorter tiles at the same LDS budget (32 tokens x 4 buffers,
+// three tiles in flight) was tried on the theory that a workgroup's K-tile period is one DMA round trip: it is not -- that variant pays
+// twice the barriers and ran 17 % slower (profiles/r02_experiments.md).
+template <typename T> struct TNShape { static constexpr int KT = 64, NST = 2; };
+template <> struct TNShape<bf16> {
+#ifdef TAV_ABL_TN_RING4
+    static constexpr int KT = 32, NST = 4;                  // measured 17 % SLOWER (942 -> 1107 us per video layer at batch 32): twice the barriers
+#else
+    static constexpr int KT = 64, NST = 2;
+#endif
+};
+
 template <typename T>
 TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     using TT = TNTile<T>;
     constexpr int ES = ET<T>::ES, PK = ET<T>::PK, KSTEP = ET<T>::KSTEP;
-    constexpr int BT = 128, KT = 64;
+    constexpr int BT = 128, KT = TNShape<T>::KT, NST = TNShape<T>::NST;
     constexpr int ROWB = TT::ROWB, CPR = TT::CPR;           // 256 B / 16 chunks (bf16), 512 B / 32 chunks (f32)
     constexpr int TILE_BYTES = KT * ROWB;
     constexpr int RPI = 64 / CPR;                           // token rows per wave instruction (4 / 2)
-    constexpr int NINST = KT / (4 * RPI);                   // DMA instructions per wave per operand per K-tile (4 / 8)
+    constexpr int WROWS = KT / 4;                           // token rows of a K-tile staged by one wave
+    constexpr int NINST = WROWS / RPI;                      // DMA instructions per wave per operand per K-tile
+    static_assert(KT % KSTEP == 0 && WROWS % RPI == 0 && NINST >= 1, "TN tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                    // [2][KT][ROWB]  dY  (n1 along the row)
-    char* sB = smem + 2 * TILE_BYTES;   // [2][KT][ROWB]  X   (n2 along the row)
+    char* sA = smem;                      // [NST][KT][ROWB]  dY  (n1 along the row)
+    char* sB = smem + NST * TILE_BYTES;   // [NST][KT][ROWB]  X   (n2 along the row)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -464,7 +478,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     const char* Ab = p.A + zb * p.a_zb * ES;
     const char* Bb = p.B + zb * p.b_zb * ES;
 
-    // DMA geometry: wave w stages token rows [16w, 16w+16) of each K-tile; instruction j covers RPI rows; lane -> (row, slot)
+    // DMA geometry: wave w stages token rows [WROWS*w, +WROWS) of each K-tile; instruction j covers RPI rows; lane -> (row, slot)
     const int lrow = lane / CPR, lslot = lane % CPR;
     // Feature columns past N1/N2: the source chunk is clamped to chunk 0 (valid memory); those outputs are never stored.
     // Token rows past the split end would pollute the sums, so a ragged last K-tile is staged by ordinary loads with
@@ -481,8 +495,8 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
 
     const int nrows = row_end - row_begin;
     const int nk = (nrows + KT - 1) / KT;
-    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 16 * ROWB);
-    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 16 * ROWB);
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * WROWS * ROWB);
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * WROWS * ROWB);
     // per-lane byte offsets of the wave's NINST source chunks in K-tile 0 (relative to the wave-uniform bases below); a K-tile
     // later is one scalar stride further, so staging costs one v_add_u32 per DMA instruction
     const char* Ab0 = Ab + ((long)row_begin * p.lda + n1_0) * ES;
@@ -490,15 +504,17 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     unsigned offA[NINST], offB[NINST];
 #pragma unroll
     for (int j = 0; j < NINST; ++j) {
-        const int trow = wave * 16 + j * RPI + lrow;               // row inside the K-tile
+        const int trow = wave * WROWS + j * RPI + lrow;            // row inside the K-tile
         int ca = TT::sw(trow, lslot); ca = ca < a_cmax ? ca : 0;
         int cb = TT::sw(trow, lslot); cb = cb < b_cmax ? cb : 0;
         offA[j] = (unsigned)(trow * p.lda * ES + ca * 16);
         offB[j] = (unsigned)(trow * p.ldb * ES + cb * 16);
     }
     const unsigned strideA = (unsigned)(KT * p.lda * ES), strideB = (unsigned)(KT * p.ldb * ES);
+    // Every stage() issues exactly 2 * NINST vector-memory instructions per wave when the tile is full (the counted waits below rely on
+    // it); the ragged tile -- always the LAST one -- goes through registers and is complete when stage() returns.
     auto stage = [&](int kt, int buf) {
-        const int base_row = row_begin + kt * KT + wave * 16;
+        const int base_row = row_begin + kt * KT + wave * WROWS;
         const bool full = (kt + 1) * KT <= nrows;               // block-uniform
         if (full) {
             const unsigned ka = kt * strideA, kb = kt * strideB;
@@ -511,7 +527,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
 #pragma unroll 1
             for (int j = 0; j < NINST; ++j) {
                 const int r = j * RPI + lrow;
-                const int trow = wave * 16 + r;
+                const int trow = wave * WROWS + r;
                 const int ca = TT::sw(trow, lslot), cb = TT::sw(trow, lslot);
                 const bool ok = (kt * KT + trow) < nrows;
                 uint4 va = make_uint4(0, 0, 0, 0), vb = va;
@@ -522,13 +538,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
             }
         }
     };
-
-    if (nk > 0) stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        wait_vmcnt0();
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    auto compute = [&](int cur) {
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
 #pragma unroll
@@ -544,14 +554,36 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
         }
-        if (do_bias) {      // column (tid & 127) of the dY tile, token rows (tid >> 7)*32 .. +31
+        if (do_bias) {      // column (tid & 127) of the dY tile, token rows (tid >> 7) * KT/2 .. + KT/2 - 1
             const int col = tid & 127, cbyte = col * ES;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const int row = (tid >> 7) * 32 + r;
+            for (int r = 0; r < KT / 2; ++r) {
+                const int row = (tid >> 7) * (KT / 2) + r;
                 bsum += ET<T>::ld(reinterpret_cast<const T*>(cA + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
             }
         }
+    };
+
+    // NST-deep ring: while tile kt is multiplied, tiles kt+1 .. kt+NST-2 are in flight and tile kt+NST-1 is issued right after the
+    // barrier (its buffer held tile kt-1, which every wave has finished).  vmcnt retires in issue order: tile kt has landed once at
+    // most (NST-2) younger tiles x 2*NINST instructions are outstanding; the last NST-2 tiles (fewer in flight, possibly the ragged
+    // one) wait for everything.
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) stage(t, t);
+    int cur = 0, kt = 0;
+    for (; kt + NST - 1 < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 2 * NINST) : "memory");
+        __syncthreads();
+        stage(kt + NST - 1, cur == 0 ? NST - 1 : cur - 1);
+        compute(cur);
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    for (; kt < nk; ++kt) {
+        wait_vmcnt0();
+        __syncthreads();
+        compute(cur);
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
     __syncthreads();
 

@@ -94,6 +94,16 @@ if "tn" in what:
         a, b = rnd(M, N1), rnd(M, N2)
         lo, med = timeit(lambda: ops.gemm_tn(a, b))
         print(f"[{tag}] gemm_tn {name:12s} M={M:6d} N1={N1:5d} N2={N2:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N1 * N2 / lo / 1e6:7.1f} TF")
+if "tng" in what:         # the four weight gradients of one encoder layer in one grouped launch (what the engine runs), per branch
+    for (name, S) in [("video", 1464), ("fusion", 481), ("audio", 249), ("text", 128)]:
+        M, H, F = B * S, 768, 3072
+        dqkv, a_lp, dy1, o_lp, du, c_lp, dy2, h_lp = rnd(M, 3 * H), rnd(M, H), rnd(M, H), rnd(M, H), rnd(M, F), rnd(M, H), rnd(M, H), rnd(M, F)
+        pairs = [(dqkv, a_lp), (dy1, o_lp), (du, c_lp), (dy2, h_lp)]
+        lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=True), iters=20, reps=5)
+        fl = 2 * M * (3 * H * H + H * H + 2 * F * H)
+        print(f"[{tag}] gemm_tn_grouped {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+        lo, med = timeit(lambda: [ops.gemm_tn(x, y, want_bias=True) for (x, y) in pairs], iters=20, reps=5)
+        print(f"[{tag}] 4 x gemm_tn (split) {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
 if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/128 x 128 with 4 waves, 8 = 256 x 128 and 16 = 256 x 256 with 8 waves)
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
                             ("video ffn2", B * 1464, 768, 3072), ("video dffn1", B * 1464, 768, 3072), ("video dqkv", B * 1464, 768, 2304),
