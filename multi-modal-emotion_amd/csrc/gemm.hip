@@ -859,22 +859,30 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         else if (nst == 3) TAV_NT_LAUNCH_S(TT, TOO, 3, NT_GEN);                                                           \
         else TAV_NT_LAUNCH_S(TT, TOO, 2, EP);                                                                             \
     } while (0)
+        // the epilogue flavours of the transformer layers as straight-line code; everything else takes the generic epilogue
+        const bool side = p.resid || p.Cpre || p.gelu_in || p.accumulate;
+        int epi = NT_GEN;
+        if (!side && p.act == 0) epi = NT_PLAIN;
+        else if (p.resid && !p.Cpre && !p.gelu_in && !p.accumulate && p.act == 0 && out_dtype == TAV_F32) epi = NT_RESID;
+        else if (p.Cpre && (p.act & 3) == 3 && !p.resid && !p.gelu_in && !p.accumulate && out_dtype == TAV_BF16) epi = NT_GELU_D;
+        else if (p.gelu_in && (p.act & 4) && !(p.act & 3) && !p.resid && !p.Cpre && !p.accumulate && out_dtype == TAV_BF16) epi = NT_MUL_D;
         if (in_dtype == TAV_FP8) {
-            if (tm == 16) {
-                if (out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8>), grid, block, lds, stream, p);
-                else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8>), grid, block, lds, stream, p);
+            if (tm == 16) {                                  // (the flavours only for the tile the video stack runs on)
+                if (out_dtype == TAV_BF16) {
+                    if (epi == NT_PLAIN) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8, NT_PLAIN>), grid, block, lds, stream, p);
+                    else if (epi == NT_GELU_D) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8, NT_GELU_D>), grid, block, lds, stream, p);
+                    else if (epi == NT_MUL_D) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8, NT_MUL_D>), grid, block, lds, stream, p);
+                    else hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 8, 8>), grid, block, lds, stream, p);
+                } else {
+                    if (epi == NT_PLAIN) hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8, NT_PLAIN>), grid, block, lds, stream, p);
+                    else if (epi == NT_RESID) hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8, NT_RESID>), grid, block, lds, stream, p);
+                    else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 8, 8>), grid, block, lds, stream, p);
+                }
             } else {
                 if (out_dtype == TAV_BF16) hipLaunchKernelGGL((gemm_nt_kernel<fp8, bf16, 4, 2, 4, 4>), grid, block, lds, stream, p);
                 else hipLaunchKernelGGL((gemm_nt_kernel<fp8, float, 4, 2, 4, 4>), grid, block, lds, stream, p);
             }
         } else if (in_dtype == TAV_BF16) {
-            // the epilogue flavours of the transformer layers as straight-line code; everything else takes the generic epilogue
-            const bool side = p.resid || p.Cpre || p.gelu_in || p.accumulate;
-            int epi = NT_GEN;
-            if (!side && p.act == 0) epi = NT_PLAIN;
-            else if (p.resid && !p.Cpre && !p.gelu_in && !p.accumulate && p.act == 0 && out_dtype == TAV_F32) epi = NT_RESID;
-            else if (p.Cpre && (p.act & 3) == 3 && !p.resid && !p.gelu_in && !p.accumulate && out_dtype == TAV_BF16) epi = NT_GELU_D;
-            else if (p.gelu_in && (p.act & 4) && !(p.act & 3) && !p.resid && !p.Cpre && !p.accumulate && out_dtype == TAV_BF16) epi = NT_MUL_D;
 #ifdef TAV_ABL_GENEPI
             epi = NT_GEN;
 #endif
