@@ -69,6 +69,8 @@ _SIGS = {
     "tav_gemm_tn_splits": (C.c_int, [i64, i64, i64, i64, C.POINTER(i32), C.POINTER(i32)]),
     "tav_gemm_tn": (C.c_int, [C.POINTER(GemmTNArgs), vp]),
     "tav_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTNProblem), i32, i64, i32, vp]),
+    "tav_gemm_tn_grouped_ws_bytes": (C.c_int64, [C.POINTER(GemmTNProblem), i32, i64, i32, i32]),
+    "tav_gemm_tn_grouped_ws": (C.c_int, [C.POINTER(GemmTNProblem), i32, i64, i32, vp, i64, i32, vp]),
     "tav_colsum": (C.c_int, [vp, i32, i64, i64, i64, vp, i32, vp, i32, vp]),
     "tav_fp8_amax_partials": (C.c_int, [i64, i64]),
     "tav_fp8_amax": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp]),

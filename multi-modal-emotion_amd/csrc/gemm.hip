@@ -631,6 +631,192 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const GemmTNGro
     gemm_tn_body<T>(grp.p[g], t - first, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 weight-gradient tile (bf16): 8 waves as 4 (n1) x 2 (n2), each a 64 x 128 block = 4 x 8 accumulator tiles, one workgroup per
+// CU.  128 FLOP per staged byte instead of 64: the 128-wide kernel is bound by the L2 -> LDS intake like its NT sibling.  The LDS image of
+// a K-tile (64 tokens) is four [64][128-feature] sub-images in the layout of TNTile<bf16> (A half 0/1, B half 0/1, 16 KB each), so the
+// transposed fragment reads are the same code; two stages = 128 KB.  A layer's four gradients are only 108 such tiles at width 768, so
+// the token axis is split over blockIdx.y into f32 slabs (or straight into dW when one split suffices) and summed in fixed order.
+template <typename T>
+TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) {
+    using TT = TNTile<T>;
+    static_assert(ET<T>::ES == 2, "bf16 only");
+    constexpr int ES = 2, KSTEP = ET<T>::KSTEP, KT = 64, ROWB = TT::ROWB;
+    constexpr int SUB = KT * ROWB;                          // one [64][128] sub-image: 16 KB
+    constexpr int STAGE = 4 * SUB;                          // A0 A1 B0 B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int w1 = wave >> 1, w2 = wave & 1;                // n1 block of 64 (0..3), n2 block of 128 (0..1)
+
+    int t1, t2;
+    if (p.tiles_1 >= p.tiles_2) { t1 = tile / p.tiles_2; t2 = tile - t1 * p.tiles_2; }
+    else { t2 = tile / p.tiles_1; t1 = tile - t2 * p.tiles_1; }
+    const int n1_0 = t1 * 256, n2_0 = t2 * 256;
+    const int row_begin = split * p.chunk_rows;
+    int row_end = row_begin + p.chunk_rows; row_end = row_end < p.rows_per_batch ? row_end : p.rows_per_batch;
+    const int nrows = row_end - row_begin;
+    const int nk = nrows > 0 ? (nrows + KT - 1) / KT : 0;
+
+    // DMA geometry: wave w stages token rows [8w, 8w+8) of each sub-image, 4 rows (x 256 B) per instruction
+    const int lrow = lane >> 4, lslot = lane & 15;
+    const int a_cmax = (p.N1 - n1_0) * ES / 16, b_cmax = (p.N2 - n2_0) * ES / 16;   // valid 16-B chunks from the tile's first column
+    const char* Ab0 = p.A + ((long)row_begin * p.lda + n1_0) * ES;
+    const char* Bb0 = p.B + ((long)row_begin * p.ldb + n2_0) * ES;
+    unsigned offA[2][2], offB[2][2];                        // [half][instruction]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int trow = wave * 8 + j * 4 + lrow;
+            int ca = 16 * h + TT::sw(trow, lslot); ca = ca < a_cmax ? ca : 0;      // columns past N1 / N2: any valid chunk (never stored)
+            int cb = 16 * h + TT::sw(trow, lslot); cb = cb < b_cmax ? cb : 0;
+            offA[h][j] = (unsigned)(trow * p.lda * ES + ca * 16);
+            offB[h][j] = (unsigned)(trow * p.ldb * ES + cb * 16);
+        }
+    const unsigned strideA = (unsigned)(KT * p.lda * ES), strideB = (unsigned)(KT * p.ldb * ES);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 8 * ROWB);
+    auto stage = [&](int kt, int buf) {
+        const bool full = (kt + 1) * KT <= nrows;               // block-uniform
+        if (full) {
+            const unsigned ka = kt * strideA, kb = kt * strideB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    glds16_s(Ab0, offA[h][j] + ka, lds0 + buf * STAGE + h * SUB + j * 1024);
+                    glds16_s(Bb0, offB[h][j] + kb, lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
+                }
+        } else {                                                    // ragged last K-tile: ordinary loads, zero fill
+#pragma unroll 1
+            for (int e = 0; e < 4; ++e) {
+                const int h = e >> 1, j = e & 1;
+                const int trow = wave * 8 + j * 4 + lrow;
+                const int c = 16 * h + TT::sw(trow, lslot);
+                const bool ok = (kt * KT + trow) < nrows;
+                const long grow = (long)row_begin + kt * KT + trow;
+                uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+                if (ok && c < a_cmax) va = *reinterpret_cast<const uint4*>(p.A + (grow * p.lda + n1_0) * ES + c * 16);
+                if (ok && c < b_cmax) vb = *reinterpret_cast<const uint4*>(p.B + (grow * p.ldb + n2_0) * ES + c * 16);
+                *reinterpret_cast<uint4*>(smem + buf * STAGE + h * SUB + trow * ROWB + lslot * 16) = va;
+                *reinterpret_cast<uint4*>(smem + buf * STAGE + (2 + h) * SUB + trow * ROWB + lslot * 16) = vb;
+            }
+        }
+    };
+
+    f32x4 acc[4][8];  // [n1 tile][n2 tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_part != nullptr && t2 == 0;
+    float bsum = 0.f;
+
+    // one DMA piece of the NEXT K-tile (8 per wave) -- issued between the MFMA groups of the first K-step: back to back right after the
+    // barrier they cost every wave of the CU ~1000 cycles of issue time at the same moment, with nothing on the matrix pipe
+    auto stage_piece = [&](int pc, unsigned ka, unsigned kb, int buf) {
+        const int h = (pc >> 1) & 1, j = pc >> 2;
+        if (pc & 1) glds16_s(Bb0, offB[h][j] + kb, lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
+        else glds16_s(Ab0, offA[h][j] + ka, lds0 + buf * STAGE + h * SUB + j * 1024);
+    };
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        wait_vmcnt0();
+        __syncthreads();
+        const bool next_full = (kt + 2) * KT <= nrows;          // block-uniform: the next tile exists and takes the DMA path
+        if (kt + 1 < nk && !next_full) stage(kt + 1, cur ^ 1);  // (ragged last tile: through registers, up front)
+        const unsigned ka = (unsigned)(kt + 1) * strideA, kb = (unsigned)(kt + 1) * strideB;
+        const char* cA = smem + cur * STAGE + (w1 >> 1) * SUB;
+        const char* cB = smem + cur * STAGE + (2 + w2) * SUB;
+#pragma unroll
+        for (int s2 = 0; s2 < KT / KSTEP; ++s2) {
+            uint4 f1[4], f2[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f1[t] = tn_frag<T>(cA, s2 * KSTEP, (w1 & 1) * 64 + t * 16, lane);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) f2[t] = tn_frag<T>(cB, s2 * KSTEP, t * 16, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
+                if (s2 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (next_full) stage_piece(b, ka, kb, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (do_bias) {      // column (tid & 255) of the dY tile, token rows (tid >> 8) * 32 .. + 31
+            const int col = tid & 255, cbyte = (col & 127) * ES;
+            const char* img = smem + cur * STAGE + (col >> 7) * SUB;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int row = (tid >> 8) * 32 + r;
+                bsum += ET<T>::ld(reinterpret_cast<const T*>(img + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
+            }
+        }
+    }
+    __syncthreads();
+
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 256 && n1_0 + tid < p.N1) p.bias_part[(long)split * p.N1 + n1_0 + tid] = red[tid] + red[256 + tid];
+    }
+    float* S = p.S + (long)split * p.N1 * p.N2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n1 = n1_0 + w1 * 64 + a * 16 + i;
+        if (n1 >= p.N1) continue;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int n2 = n2_0 + w2 * 128 + b * 16 + 4 * g;
+            if (n2 >= p.N2) continue;
+            st4(S + (long)n1 * p.N2 + n2, acc[a][b]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_grouped_big_kernel(const GemmTNGroup grp) {
+    const int t = xcd_remap(blockIdx.x, grp.tile_end[grp.n - 1]);
+    int g = 0;
+#pragma unroll
+    for (int k = 0; k < TN_GROUP_MAX - 1; ++k) g += (k < grp.n - 1 && t >= grp.tile_end[k]) ? 1 : 0;
+    const int first = g == 0 ? 0 : grp.tile_end[g - 1];
+    gemm_tn_big_body<T>(grp.p[g], t - first, blockIdx.y);
+}
+
+// dW_k = sum_s slab_k[s], db_k = sum_s bias_part_k[s] for the problems of one grouped launch (fixed order: bitwise reproducible)
+struct TNGroupReduce {
+    const float* slabs[TN_GROUP_MAX]; float* out[TN_GROUP_MAX]; const float* bias_part[TN_GROUP_MAX]; float* dbias[TN_GROUP_MAX];
+    long n4[TN_GROUP_MAX];          // N1 * N2 / 4 per problem
+    long end4[TN_GROUP_MAX];        // prefix sums of n4
+    int N1[TN_GROUP_MAX];
+    int n, nsplit;
+};
+__global__ void tn_group_reduce_kernel(const TNGroupReduce r) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= r.end4[r.n - 1]) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < TN_GROUP_MAX - 1; ++q) k += (q < r.n - 1 && gid >= r.end4[q]) ? 1 : 0;
+    const long local = gid - (k == 0 ? 0 : r.end4[k - 1]);
+    const float* S = r.slabs[k];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < r.nsplit; ++s2) v += ld4(S + ((long)s2 * r.n4[k] + local) * 4);
+    st4(r.out[k] + local * 4, v);
+    if (r.dbias[k] && local < r.N1[k]) {                     // the first N1 threads of a problem also finish its bias gradient
+        float b = 0.f;
+        for (int s2 = 0; s2 < r.nsplit; ++s2) b += r.bias_part[k][(long)s2 * r.N1[k] + local];
+        r.dbias[k][local] = b;
+    }
+}
+
 // out[n1][perm(n2)] (+)= sum_s S[s][n1][n2];  perm(n2) = (n2 % inner) * outer + n2 / inner  (outer = 1: identity).
 // Used with inner = C_in, outer = kernel width to hand conv wgrads back in nn.Conv1d's [co][ci][k] order.
 __global__ void splitk_reduce_kernel(const float* __restrict__ S, float* __restrict__ out, int nsplit, long n_elems, int N2,
@@ -987,6 +1173,85 @@ extern "C" int tav_gemm_tn_grouped(const tav_gemm_tn_problem* probs, int32_t npr
     dim3 grid(total), block(256);
     if (dtype == TAV_BF16) hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16>), grid, block, 4 * 64 * 256, stream, grp);
     else hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), grid, block, 4 * 64 * 512, stream, grp);
+    return (int)hipGetLastError();
+}
+
+// Plan of a grouped launch: 256-wide tiles + `nsplit` token chunks when the problems are large enough to pay for the slabs, else the
+// 128-wide kernel (every tile sums over all rows, no workspace).  flags: bit 0 forces the 256-wide form, bit 1 the 128-wide one,
+// bits 8..11 an explicit split count (tests / tuning).
+static bool tn_big_plan(const tav_gemm_tn_problem* probs, int nprob, long rows, int dtype, int flags, int* nsplit, long* ws_floats) {
+    *nsplit = 1; *ws_floats = 0;
+    if (dtype != TAV_BF16 || (flags & 2)) return false;
+    long tiles = 0, elems = 0, n1sum = 0;
+    for (int k = 0; k < nprob; ++k) {
+        tiles += ((probs[k].N1 + 255) / 256) * ((probs[k].N2 + 255) / 256);
+        elems += probs[k].N1 * probs[k].N2; n1sum += probs[k].N1;
+    }
+    if (!(flags & 1) && (rows < 6144 || tiles < 48)) return false;    // small problems: prologue / slab traffic dominate
+    int best = 1; double best_score = -1.0;
+    for (int s2 = 1; s2 <= 4; ++s2) {
+        if (s2 > 1 && rows / s2 < 2048) break;
+        const long wgs = tiles * s2;
+        const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+        const double score = fill - 0.04 * (s2 - 1);                 // each extra split writes and re-reads one more f32 copy of the gradients
+        if (score > best_score + 1e-9) { best_score = score; best = s2; }
+    }
+    if ((flags >> 8) & 15) best = (flags >> 8) & 15;
+    *nsplit = best;
+    *ws_floats = best > 1 ? (long)best * (elems + n1sum) : 0;
+    return true;
+}
+
+extern "C" int64_t tav_gemm_tn_grouped_ws_bytes(const tav_gemm_tn_problem* probs, int32_t nprob, int64_t rows, int32_t dtype, int32_t flags) {
+    if (!probs || nprob <= 0 || nprob > TN_GROUP_MAX || rows <= 0) return 0;
+    int ns; long wsf;
+    return tn_big_plan(probs, nprob, rows, dtype, flags, &ns, &wsf) ? wsf * 4 : 0;
+}
+
+extern "C" int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* probs, int32_t nprob, int64_t rows, int32_t dtype, void* workspace,
+                                      int64_t workspace_bytes, int32_t flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!probs) return TAV_ERR_NULL;
+    if (nprob <= 0 || nprob > TN_GROUP_MAX || rows <= 0) return TAV_ERR_SHAPE;
+    int nsplit; long wsf;
+    if (!tn_big_plan(probs, nprob, rows, dtype, flags, &nsplit, &wsf)) return tav_gemm_tn_grouped(probs, nprob, rows, dtype, stream_);
+    if (wsf > 0 && (!workspace || workspace_bytes < wsf * 4)) return TAV_ERR_NULL;
+    GemmTNGroup grp;
+    TNGroupReduce red;
+    int total = 0;
+    long chunk = ((rows + nsplit - 1) / nsplit + 63) / 64 * 64;
+    if ((long)(nsplit - 1) * chunk >= rows) return TAV_ERR_SHAPE;      // (an empty split would leave its slab unwritten)
+    float* ws = (float*)workspace;
+    long ws_off = 0, end4 = 0;
+    for (int k = 0; k < TN_GROUP_MAX; ++k) {
+        const tav_gemm_tn_problem& a = probs[k < nprob ? k : nprob - 1];
+        if (k < nprob) {
+            if (!a.A || !a.B || !a.out) return TAV_ERR_NULL;
+            if (a.N1 <= 0 || a.N2 <= 0 || a.N1 % 8 || a.N2 % 8) return TAV_ERR_SHAPE;
+            if (a.lda % 8 || a.ldb % 8) return TAV_ERR_ALIGN;
+            if ((rows + 64) * (a.lda > a.ldb ? a.lda : a.ldb) * 2 >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
+        }
+        GemmTN& p = grp.p[k];
+        p.A = (const char*)a.A; p.B = (const char*)a.B; p.N1 = (int)a.N1; p.N2 = (int)a.N2; p.lda = a.lda; p.ldb = a.ldb;
+        p.rows_per_batch = (int)rows; p.a_zb = 0; p.b_zb = 0; p.chunk_rows = (int)chunk; p.chunks_per_batch = nsplit;
+        p.tiles_1 = (p.N1 + 255) / 256; p.tiles_2 = (p.N2 + 255) / 256;
+        if (nsplit > 1) { p.S = ws + ws_off; if (k < nprob) ws_off += (long)nsplit * a.N1 * a.N2; }
+        else p.S = a.out;
+        p.bias_part = nullptr;
+        if (k < nprob) total += p.tiles_1 * p.tiles_2;
+        grp.tile_end[k] = total;
+        red.slabs[k] = p.S; red.out[k] = a.out; red.dbias[k] = a.dbias; red.N1[k] = (int)a.N1; red.n4[k] = a.N1 * a.N2 / 4;
+        if (k < nprob) end4 += red.n4[k];
+        red.end4[k] = end4;
+    }
+    for (int k = 0; k < TN_GROUP_MAX; ++k) {                            // bias partials behind all slabs (or the final db when unsplit)
+        const tav_gemm_tn_problem& a = probs[k < nprob ? k : nprob - 1];
+        if (nsplit > 1) { grp.p[k].bias_part = a.dbias ? ws + ws_off : nullptr; red.bias_part[k] = grp.p[k].bias_part; if (k < nprob && a.dbias) ws_off += (long)nsplit * a.N1; }
+        else { grp.p[k].bias_part = a.dbias; red.bias_part[k] = nullptr; }
+    }
+    grp.n = nprob; red.n = nprob; red.nsplit = nsplit;
+    hipLaunchKernelGGL((gemm_tn_grouped_big_kernel<bf16>), dim3(total, nsplit), dim3(512), 2 * 4 * 64 * 256, stream, grp);
+    if (nsplit > 1) hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)((end4 + 255) / 256)), dim3(256), 0, stream, red);
     return (int)hipGetLastError();
 }
 

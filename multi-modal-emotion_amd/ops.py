@@ -124,9 +124,10 @@ def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb
     return (out, dbias) if want_bias else out
 
 
-def gemm_tn_grouped(pairs, want_bias=True):
+def gemm_tn_grouped(pairs, want_bias=True, flags=0):
     """[(A_k [rows, N1_k], B_k [rows, N2_k]), ...] (<= 4, same rows and dtype) -> [(dW_k [N1_k, N2_k] f32, db_k [N1_k] f32 | None), ...]
-    in ONE launch, every tile summing over all rows (the weight gradients of one transformer layer)."""
+    in ONE launch (the weight gradients of one transformer layer): 128-wide tiles that each sum over all rows, or -- bf16, large problems --
+    256-wide tiles with the rows split over workgroups into f32 slabs plus a fixed-order reduce (the library decides; `flags` as in tavhip.h)."""
     n = len(pairs)
     rows, dtype = pairs[0][0].shape[0], pairs[0][0].dtype
     probs = (L.GemmTNProblem * n)()
@@ -140,7 +141,9 @@ def gemm_tn_grouped(pairs, want_bias=True):
         pr.A, pr.B, pr.out, pr.dbias = ptr(a), ptr(b), ptr(dW), ptr(db)
         pr.N1, pr.N2, pr.lda, pr.ldb = N1, N2, a.stride(0), b.stride(0)
         outs.append((dW, db))
-    check(lib().tav_gemm_tn_grouped(probs, n, rows, dt(pairs[0][0]), stream()), "gemm_tn_grouped")
+    nbytes = lib().tav_gemm_tn_grouped_ws_bytes(probs, n, rows, dt(pairs[0][0]), flags)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pairs[0][0].device) if nbytes > 0 else None
+    check(lib().tav_gemm_tn_grouped_ws(probs, n, rows, dt(pairs[0][0]), ptr(ws), nbytes, flags, stream()), "gemm_tn_grouped")
     return outs
 
 

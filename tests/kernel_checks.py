@@ -177,6 +177,33 @@ def check_gemm_tn_grouped(dtype, M=777):
     return rs
 
 
+def check_gemm_tn_grouped_big(M=5000, flags=1):
+    """The 256-wide weight-gradient tile (bf16): ragged N1 / N2 (not multiples of 256), a ragged last K-tile, operands that are column slices
+    of wider buffers, one to three token splits with the fixed-order slab reduce -- against f32 matmuls; and twice for bitwise reproducibility."""
+    dtype = torch.bfloat16
+    shapes = [(384, 136), (136, 264), (256, 512), (520, 128)]
+    wide_a = _rnd(M, 640, dtype=dtype, seed=51)
+    pairs, refs = [], []
+    for k, (n1, n2) in enumerate(shapes):
+        a = wide_a[:, 64:64 + n1] if k == 0 else _rnd(M, n1, dtype=dtype, seed=52 + k)
+        b = _rnd(M, n2, dtype=dtype, seed=60 + k)
+        pairs.append((a, b))
+        refs.append((a.float().t() @ b.float(), a.float().sum(0)))
+    rs = []
+    for nsplit in (1, 2, 3):
+        outs = ops.gemm_tn_grouped(pairs, want_bias=True, flags=flags | (nsplit << 8))
+        again = ops.gemm_tn_grouped(pairs, want_bias=True, flags=flags | (nsplit << 8))
+        for k, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
+            rs.append(_res(f"gemm_tn_grouped.big[M{M},splits{nsplit}].dW{k}", dW, rW, 2e-3))
+            rs.append(_res(f"gemm_tn_grouped.big[M{M},splits{nsplit}].db{k}", db, rb, 1e-5))
+        same = all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(outs, again))
+        rs.append((f"gemm_tn_grouped.big[splits{nsplit}] bitwise repeatable", 0.0 if same else 1.0, 0.0, bool(same)))
+    small = ops.gemm_tn_grouped(pairs, want_bias=True, flags=2)
+    for k, ((dW, db), (rW, rb)) in enumerate(zip(small, refs)):
+        rs.append(_res(f"gemm_tn_grouped.small(flag)[M{M}].dW{k}", dW, rW, 2e-3))
+    return rs
+
+
 def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
     """Conv1d(C,C,k,stride s) on channels-last activations as an NT GEMM over overlapping rows + its gradients."""
     T_out = (T_in - k) // s + 1
@@ -507,6 +534,8 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
         if dtype == torch.bfloat16:
             out.append(check_gemm_nt_mixed_schedule)
+        if dtype == torch.bfloat16:
+            out.append(check_gemm_tn_grouped_big)
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_nt_gelu_derivative_pair(d))
         if dtype == torch.bfloat16:

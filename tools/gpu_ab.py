@@ -102,8 +102,11 @@ if "tng" in what:         # the four weight gradients of one encoder layer in on
         lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=True), iters=20, reps=5)
         fl = 2 * M * (3 * H * H + H * H + 2 * F * H)
         print(f"[{tag}] gemm_tn_grouped {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
-        lo, med = timeit(lambda: [ops.gemm_tn(x, y, want_bias=True) for (x, y) in pairs], iters=20, reps=5)
-        print(f"[{tag}] 4 x gemm_tn (split) {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+        for fl_name, flg in (("128-wide tiles", 2), ("256-wide x1", 1 | (1 << 8)), ("256-wide x2", 1 | (2 << 8)), ("256-wide x3", 1 | (3 << 8))):
+            if (flg >> 8) > 1 and M // (flg >> 8) < 64:
+                continue
+            lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=True, flags=flg), iters=20, reps=5)
+            print(f"[{tag}]   {fl_name:15s} {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
 if "tiles" in what:       # NT GEMM: workgroup tile sweep (hint 2/3/4 = 64/96/128 x 128 with 4 waves, 8 = 256 x 128 and 16 = 256 x 256 with 8 waves)
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
                             ("video ffn2", B * 1464, 768, 3072), ("video dffn1", B * 1464, 768, 3072), ("video dqkv", B * 1464, 768, 2304),
