@@ -111,11 +111,13 @@ typedef struct tav_gemm_tn_problem {
     int64_t N1, N2, lda, ldb;
 } tav_gemm_tn_problem;
 int tav_gemm_tn_grouped(const tav_gemm_tn_problem* problems, int32_t nproblems, int64_t rows, int32_t dtype, void* stream);
-/* The same with a caller-provided workspace, which lets the library use its 256 x 256 tile with the token axis split over
- * workgroups (bf16, large problems: the four gradients of a 768-wide layer are only 108 such tiles): f32 slabs in the workspace, summed in a
- * fixed order by a second kernel (bitwise reproducible, no atomics).  tav_gemm_tn_grouped_ws_bytes() returns the size the plan for these
- * problems needs (0: none -- the call then is tav_gemm_tn_grouped).  flags: 0 = library's choice; bit 0 forces the 256-wide form, bit 1 the
- * 128-wide one, bits 8-11 an explicit split count (tests / tuning). */
+/* The same with a caller-provided workspace, which lets the library (a) use its 256 x 256 tile with the token axis split over workgroups
+ * (bf16, large problems: the four gradients of a 768-wide layer are only 108 such tiles) -- f32 slabs in the workspace, summed in a fixed
+ * order by a second kernel -- and (b) share the bias-gradient column sums among the tiles of a tile row instead of loading them all onto
+ * the first tile (partials in the workspace, summed by the same / a tiny second kernel).  Bitwise reproducible, no atomics.
+ * tav_gemm_tn_grouped_ws_bytes() returns the size the plan for these problems needs; with a smaller (or NULL) workspace the call falls back
+ * to tav_gemm_tn_grouped.  flags: 0 = library's choice; bit 0 forces the 256-wide form, bit 1 the 128-wide one, bits 8-11 an explicit
+ * split count (tests / tuning). */
 int64_t tav_gemm_tn_grouped_ws_bytes(const tav_gemm_tn_problem* problems, int32_t nproblems, int64_t rows, int32_t dtype, int32_t flags);
 int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* problems, int32_t nproblems, int64_t rows, int32_t dtype, void* workspace,
                            int64_t workspace_bytes, int32_t flags, void* stream);

@@ -390,7 +390,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 // ------------------------------------------------------------------------------------------------
 struct GemmTN {
     const char* A; const char* B; float* S;   // S: slabs [nsplit][N1][N2] fp32
-    float* bias_part;       // optional [nsplit][N1]: column sums of A (the bias gradient), written by the t2 == 0 tiles
+    float* bias_part;       // optional column sums of A (the bias gradient): [nsplit][N1] written by the t2 == 0 tiles, or -- bias_spread --
+                            // [nsplit][tiles_2][N1]: tile (t1, t2) sums the K-tiles with kt % tiles_2 == t2, so the work is shared by a tile row
+    int bias_spread;
     int N1, N2;
     long lda, ldb;          // row strides (elements) of the token-major operands
     int rows_per_batch;     // T: tokens per batch entry (reduction axis = nbatch * T)
@@ -490,7 +492,10 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = p.bias_part != nullptr && t2 == 0;
+    // The column sums read 32 two-byte LDS values per thread and K-tile: on the t2 == 0 tiles alone they made those tiles (and with them the
+    // launch) 7-30 % longer; spread over the tile row every tile pays 1/tiles_2 of it.
+    const bool do_bias = p.bias_part != nullptr && (p.bias_spread || t2 == 0);
+    const int bias_mod = p.bias_spread ? p.tiles_2 : 1, bias_rem = p.bias_spread ? t2 : 0;
     float bsum = 0.f;
 
     const int nrows = row_end - row_begin;
@@ -538,7 +543,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
             }
         }
     };
-    auto compute = [&](int cur) {
+    auto compute = [&](int cur, int kt_now) {
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
 #pragma unroll
@@ -554,7 +559,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
         }
-        if (do_bias) {      // column (tid & 127) of the dY tile, token rows (tid >> 7) * KT/2 .. + KT/2 - 1
+        if (do_bias && (kt_now % bias_mod) == bias_rem) {      // column (tid & 127) of the dY tile, token rows (tid >> 7) * KT/2 .. + KT/2 - 1
             const int col = tid & 127, cbyte = col * ES;
 #pragma unroll 8
             for (int r = 0; r < KT / 2; ++r) {
@@ -576,13 +581,13 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 2 * NINST) : "memory");
         __syncthreads();
         stage(kt + NST - 1, cur == 0 ? NST - 1 : cur - 1);
-        compute(cur);
+        compute(cur, kt);
         cur = cur + 1 == NST ? 0 : cur + 1;
     }
     for (; kt < nk; ++kt) {
         wait_vmcnt0();
         __syncthreads();
-        compute(cur);
+        compute(cur, kt);
         cur = cur + 1 == NST ? 0 : cur + 1;
     }
     __syncthreads();
@@ -591,7 +596,8 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 128 && n1_0 + tid < p.N1) p.bias_part[(long)split * p.N1 + n1_0 + tid] = red[tid] + red[128 + tid];
+        const long slot = p.bias_spread ? (long)split * p.tiles_2 + t2 : split;
+        if (tid < 128 && n1_0 + tid < p.N1) p.bias_part[slot * p.N1 + n1_0 + tid] = red[tid] + red[128 + tid];
     }
     float* S = p.S + (long)split * p.N1 * p.N2;
 #pragma unroll
@@ -710,7 +716,8 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = p.bias_part != nullptr && t2 == 0;
+    const bool do_bias = p.bias_part != nullptr && (p.bias_spread || t2 == 0);
+    const int bias_mod = p.bias_spread ? p.tiles_2 : 1, bias_rem = p.bias_spread ? t2 : 0;
     float bsum = 0.f;
 
     // one DMA piece of the NEXT K-tile (8 per wave) -- issued between the MFMA groups of the first K-step: back to back right after the
@@ -749,7 +756,7 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
                 }
             }
         }
-        if (do_bias) {      // column (tid & 255) of the dY tile, token rows (tid >> 8) * 32 .. + 31
+        if (do_bias && (kt % bias_mod) == bias_rem) {      // column (tid & 255) of the dY tile, token rows (tid >> 8) * 32 .. + 31
             const int col = tid & 255, cbyte = (col & 127) * ES;
             const char* img = smem + cur * STAGE + (col >> 7) * SUB;
 #pragma unroll 8
@@ -765,7 +772,8 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 256 && n1_0 + tid < p.N1) p.bias_part[(long)split * p.N1 + n1_0 + tid] = red[tid] + red[256 + tid];
+        const long slot = p.bias_spread ? (long)split * p.tiles_2 + t2 : split;
+        if (tid < 256 && n1_0 + tid < p.N1) p.bias_part[slot * p.N1 + n1_0 + tid] = red[tid] + red[256 + tid];
     }
     float* S = p.S + (long)split * p.N1 * p.N2;
 #pragma unroll
@@ -797,6 +805,7 @@ struct TNGroupReduce {
     long n4[TN_GROUP_MAX];          // N1 * N2 / 4 per problem
     long end4[TN_GROUP_MAX];        // prefix sums of n4
     int N1[TN_GROUP_MAX];
+    int nbias[TN_GROUP_MAX];       // bias partial slots per problem (splits x tiles sharing the sums)
     int n, nsplit;
 };
 __global__ void tn_group_reduce_kernel(const TNGroupReduce r) {
@@ -812,9 +821,20 @@ __global__ void tn_group_reduce_kernel(const TNGroupReduce r) {
     st4(r.out[k] + local * 4, v);
     if (r.dbias[k] && local < r.N1[k]) {                     // the first N1 threads of a problem also finish its bias gradient
         float b = 0.f;
-        for (int s2 = 0; s2 < r.nsplit; ++s2) b += r.bias_part[k][(long)s2 * r.N1[k] + local];
+        for (int s2 = 0; s2 < r.nbias[k]; ++s2) b += r.bias_part[k][(long)s2 * r.N1[k] + local];
         r.dbias[k][local] = b;
     }
+}
+// the bias gradients alone (unsplit launches: the tiles wrote dW themselves); grid covers the N1 of all problems
+__global__ void tn_group_bias_reduce_kernel(const TNGroupReduce r, int total_n1) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_n1) return;
+    int k = 0;
+    while (k < r.n - 1 && gid >= r.N1[k]) { gid -= r.N1[k]; ++k; }
+    if (!r.dbias[k]) return;
+    float b = 0.f;
+    for (int s2 = 0; s2 < r.nbias[k]; ++s2) b += r.bias_part[k][(long)s2 * r.N1[k] + gid];
+    r.dbias[k][gid] = b;
 }
 
 // out[n1][perm(n2)] (+)= sum_s S[s][n1][n2];  perm(n2) = (n2 % inner) * outer + n2 / inner  (outer = 1: identity).
@@ -1161,7 +1181,7 @@ extern "C" int tav_gemm_tn_grouped(const tav_gemm_tn_problem* probs, int32_t npr
             if ((rows + 64) * (a.lda > a.ldb ? a.lda : a.ldb) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
         }
         GemmTN& p = grp.p[k];
-        p.A = (const char*)a.A; p.B = (const char*)a.B; p.S = a.out; p.bias_part = a.dbias;
+        p.A = (const char*)a.A; p.B = (const char*)a.B; p.S = a.out; p.bias_part = a.dbias; p.bias_spread = 0;
         p.N1 = (int)a.N1; p.N2 = (int)a.N2; p.lda = a.lda; p.ldb = a.ldb;
         p.rows_per_batch = (int)rows; p.a_zb = 0; p.b_zb = 0;
         p.chunk_rows = (int)(((rows + 63) / 64) * 64); p.chunks_per_batch = 1;
@@ -1181,31 +1201,39 @@ extern "C" int tav_gemm_tn_grouped(const tav_gemm_tn_problem* probs, int32_t npr
 // bits 8..11 an explicit split count (tests / tuning).
 static bool tn_big_plan(const tav_gemm_tn_problem* probs, int nprob, long rows, int dtype, int flags, int* nsplit, long* ws_floats) {
     *nsplit = 1; *ws_floats = 0;
-    if (dtype != TAV_BF16 || (flags & 2)) return false;
-    long tiles = 0, elems = 0, n1sum = 0;
+    const bool can_big = dtype == TAV_BF16 && !(flags & 2);
+    long tiles = 0, elems = 0;
     for (int k = 0; k < nprob; ++k) {
         tiles += ((probs[k].N1 + 255) / 256) * ((probs[k].N2 + 255) / 256);
-        elems += probs[k].N1 * probs[k].N2; n1sum += probs[k].N1;
+        elems += probs[k].N1 * probs[k].N2;
     }
-    if (!(flags & 1) && (rows < 6144 || tiles < 48)) return false;    // small problems: prologue / slab traffic dominate
-    int best = 1; double best_score = -1.0;
-    for (int s2 = 1; s2 <= 4; ++s2) {
-        if (s2 > 1 && rows / s2 < 2048) break;
-        const long wgs = tiles * s2;
-        const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
-        const double score = fill - 0.04 * (s2 - 1);                 // each extra split writes and re-reads one more f32 copy of the gradients
-        if (score > best_score + 1e-9) { best_score = score; best = s2; }
+    bool big = can_big && ((flags & 1) || (rows >= 12288 && tiles >= 48));  // below: the 128-wide tiles (slab traffic, 84 % fill) are as fast or faster
+    if (big) {
+        int best = 1; double best_score = -1.0;
+        for (int s2 = 1; s2 <= 4; ++s2) {
+            if (s2 > 1 && rows / s2 < 2048) break;
+            const long wgs = tiles * s2;
+            const double fill = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+            const double score = fill - 0.04 * (s2 - 1);             // each extra split writes and re-reads one more f32 copy of the gradients
+            if (score > best_score + 1e-9) { best_score = score; best = s2; }
+        }
+        if ((flags >> 8) & 15) best = (flags >> 8) & 15;
+        *nsplit = best;
     }
-    if ((flags >> 8) & 15) best = (flags >> 8) & 15;
-    *nsplit = best;
-    *ws_floats = best > 1 ? (long)best * (elems + n1sum) : 0;
-    return true;
+    // workspace: the slabs of a split launch, then the bias partials [nsplit][tiles_2][N1] of every problem that wants a bias gradient
+    const int tw = big ? 256 : 128;
+    long wsf = *nsplit > 1 ? (long)*nsplit * elems : 0;
+    for (int k = 0; k < nprob; ++k)
+        if (probs[k].dbias) wsf += (long)*nsplit * ((probs[k].N2 + tw - 1) / tw) * probs[k].N1;
+    *ws_floats = wsf;
+    return big;
 }
 
 extern "C" int64_t tav_gemm_tn_grouped_ws_bytes(const tav_gemm_tn_problem* probs, int32_t nprob, int64_t rows, int32_t dtype, int32_t flags) {
     if (!probs || nprob <= 0 || nprob > TN_GROUP_MAX || rows <= 0) return 0;
     int ns; long wsf;
-    return tn_big_plan(probs, nprob, rows, dtype, flags, &ns, &wsf) ? wsf * 4 : 0;
+    tn_big_plan(probs, nprob, rows, dtype, flags, &ns, &wsf);
+    return wsf * 4;
 }
 
 extern "C" int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* probs, int32_t nprob, int64_t rows, int32_t dtype, void* workspace,
@@ -1213,13 +1241,16 @@ extern "C" int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* probs, int32_t 
     hipStream_t stream = (hipStream_t)stream_;
     if (!probs) return TAV_ERR_NULL;
     if (nprob <= 0 || nprob > TN_GROUP_MAX || rows <= 0) return TAV_ERR_SHAPE;
+    if (dtype != TAV_BF16 && dtype != TAV_F32) return TAV_ERR_DTYPE;
     int nsplit; long wsf;
-    if (!tn_big_plan(probs, nprob, rows, dtype, flags, &nsplit, &wsf)) return tav_gemm_tn_grouped(probs, nprob, rows, dtype, stream_);
-    if (wsf > 0 && (!workspace || workspace_bytes < wsf * 4)) return TAV_ERR_NULL;
+    const bool big = tn_big_plan(probs, nprob, rows, dtype, flags, &nsplit, &wsf);
+    if (wsf > 0 && (!workspace || workspace_bytes < wsf * 4)) return tav_gemm_tn_grouped(probs, nprob, rows, dtype, stream_);   // no room: the workspace-free form
+    const int es = dtype == TAV_BF16 ? 2 : 4, pk = 16 / es, tw = big ? 256 : 128;
     GemmTNGroup grp;
     TNGroupReduce red;
-    int total = 0;
-    long chunk = ((rows + nsplit - 1) / nsplit + 63) / 64 * 64;
+    int total = 0, total_n1 = 0;
+    bool any_bias = false;
+    const long chunk = ((rows + nsplit - 1) / nsplit + 63) / 64 * 64;
     if ((long)(nsplit - 1) * chunk >= rows) return TAV_ERR_SHAPE;      // (an empty split would leave its slab unwritten)
     float* ws = (float*)workspace;
     long ws_off = 0, end4 = 0;
@@ -1227,31 +1258,35 @@ extern "C" int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* probs, int32_t 
         const tav_gemm_tn_problem& a = probs[k < nprob ? k : nprob - 1];
         if (k < nprob) {
             if (!a.A || !a.B || !a.out) return TAV_ERR_NULL;
-            if (a.N1 <= 0 || a.N2 <= 0 || a.N1 % 8 || a.N2 % 8) return TAV_ERR_SHAPE;
-            if (a.lda % 8 || a.ldb % 8) return TAV_ERR_ALIGN;
-            if ((rows + 64) * (a.lda > a.ldb ? a.lda : a.ldb) * 2 >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
+            if (a.N1 <= 0 || a.N2 <= 0 || a.N1 % pk || a.N2 % pk || a.N2 % 4) return TAV_ERR_SHAPE;
+            if (a.lda % pk || a.ldb % pk) return TAV_ERR_ALIGN;
+            if ((rows + 64) * (a.lda > a.ldb ? a.lda : a.ldb) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
         }
         GemmTN& p = grp.p[k];
         p.A = (const char*)a.A; p.B = (const char*)a.B; p.N1 = (int)a.N1; p.N2 = (int)a.N2; p.lda = a.lda; p.ldb = a.ldb;
         p.rows_per_batch = (int)rows; p.a_zb = 0; p.b_zb = 0; p.chunk_rows = (int)chunk; p.chunks_per_batch = nsplit;
-        p.tiles_1 = (p.N1 + 255) / 256; p.tiles_2 = (p.N2 + 255) / 256;
+        p.tiles_1 = (p.N1 + tw - 1) / tw; p.tiles_2 = (p.N2 + tw - 1) / tw;
         if (nsplit > 1) { p.S = ws + ws_off; if (k < nprob) ws_off += (long)nsplit * a.N1 * a.N2; }
         else p.S = a.out;
-        p.bias_part = nullptr;
+        p.bias_part = nullptr; p.bias_spread = 1;
         if (k < nprob) total += p.tiles_1 * p.tiles_2;
         grp.tile_end[k] = total;
         red.slabs[k] = p.S; red.out[k] = a.out; red.dbias[k] = a.dbias; red.N1[k] = (int)a.N1; red.n4[k] = a.N1 * a.N2 / 4;
-        if (k < nprob) end4 += red.n4[k];
+        red.nbias[k] = nsplit * p.tiles_2; red.bias_part[k] = nullptr;
+        if (k < nprob) { end4 += red.n4[k]; total_n1 += (int)a.N1; any_bias |= a.dbias != nullptr; }
         red.end4[k] = end4;
     }
-    for (int k = 0; k < TN_GROUP_MAX; ++k) {                            // bias partials behind all slabs (or the final db when unsplit)
-        const tav_gemm_tn_problem& a = probs[k < nprob ? k : nprob - 1];
-        if (nsplit > 1) { grp.p[k].bias_part = a.dbias ? ws + ws_off : nullptr; red.bias_part[k] = grp.p[k].bias_part; if (k < nprob && a.dbias) ws_off += (long)nsplit * a.N1; }
-        else { grp.p[k].bias_part = a.dbias; red.bias_part[k] = nullptr; }
+    for (int k = 0; k < nprob; ++k) {                                   // bias partials behind all slabs
+        if (!probs[k].dbias) continue;
+        grp.p[k].bias_part = ws + ws_off; red.bias_part[k] = ws + ws_off;
+        ws_off += (long)red.nbias[k] * probs[k].N1;
     }
     grp.n = nprob; red.n = nprob; red.nsplit = nsplit;
-    hipLaunchKernelGGL((gemm_tn_grouped_big_kernel<bf16>), dim3(total, nsplit), dim3(512), 2 * 4 * 64 * 256, stream, grp);
+    if (big) hipLaunchKernelGGL((gemm_tn_grouped_big_kernel<bf16>), dim3(total, nsplit), dim3(512), 2 * 4 * 64 * 256, stream, grp);
+    else if (dtype == TAV_BF16) hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16>), dim3(total), dim3(256), 4 * 64 * 256, stream, grp);
+    else hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), dim3(total), dim3(256), 4 * 64 * 512, stream, grp);
     if (nsplit > 1) hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)((end4 + 255) / 256)), dim3(256), 0, stream, red);
+    else if (any_bias) hipLaunchKernelGGL(tn_group_bias_reduce_kernel, dim3((unsigned)((total_n1 + 255) / 256)), dim3(256), 0, stream, red, total_n1);
     return (int)hipGetLastError();
 }
 
@@ -1267,7 +1302,7 @@ extern "C" int tav_gemm_tn(const tav_gemm_tn_args* a, void* stream_) {
     if ((a->rows_per_batch + 64) * (a->lda > a->ldb ? a->lda : a->ldb) * es >= (1ll << 32)) return TAV_ERR_SHAPE;   // 32-bit staging offsets
     GemmTN p;
     p.A = (const char*)a->A; p.B = (const char*)a->B; p.S = a->slabs;
-    p.bias_part = a->dbias ? a->bias_partials : nullptr;
+    p.bias_part = a->dbias ? a->bias_partials : nullptr; p.bias_spread = 0;
     if (a->dbias && !a->bias_partials) return TAV_ERR_NULL;
     p.N1 = (int)a->N1; p.N2 = (int)a->N2; p.lda = a->lda; p.ldb = a->ldb;
     p.rows_per_batch = (int)a->rows_per_batch; p.a_zb = a->a_zb; p.b_zb = a->b_zb;

@@ -102,6 +102,8 @@ if "tng" in what:         # the four weight gradients of one encoder layer in on
         lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=True), iters=20, reps=5)
         fl = 2 * M * (3 * H * H + H * H + 2 * F * H)
         print(f"[{tag}] gemm_tn_grouped {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+        lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=False), iters=20, reps=5)
+        print(f"[{tag}]   (no bias sums)  {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
         for fl_name, flg in (("128-wide tiles", 2), ("256-wide x1", 1 | (1 << 8)), ("256-wide x2", 1 | (2 << 8)), ("256-wide x3", 1 | (3 << 8))):
             if (flg >> 8) > 1 and M // (flg >> 8) < 64:
                 continue
