@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH, help="utterances per step over ALL GPUs (strong scaling: 32/N per rank)")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="> 0: weak-scaling variant, this many utterances on every GPU")
     ap.add_argument("--preset", default="B")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8", "fp8-all"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8", "fp8-all", "fp8-wgrad8"],
                     help="fp8: e4m3 operands (per-tensor scales) in the linear layers of every transformer block, the rest as bf16 (BASELINE config 5)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -28,7 +28,7 @@ def bump_weight_epoch():
 class Policy:
     def __init__(self, name="bf16"):
         name = {"bfloat16": "bf16", "float32": "fp32", "f32": "fp32", "float8": "fp8", "e4m3": "fp8"}.get(name, name)
-        if name not in ("bf16", "fp32", "fp8", "fp8-all"):
+        if name not in ("bf16", "fp32", "fp8", "fp8-all", "fp8-wgrad8"):
             raise ValueError(f"unknown precision policy {name!r}")
         self.name = name
         # "fp8" (BASELINE config 5): the four linear layers of every VIDEO-encoder block (forward, dgrad, wgrad) run on e4m3 operands with
@@ -39,7 +39,11 @@ class Policy:
         self.lp = torch.float32 if name == "fp32" else torch.bfloat16
         self.f32 = name == "fp32"
         self.fp8 = name.startswith("fp8")
-        self.fp8_stacks = () if not self.fp8 else (("video",) if name == "fp8" else ("video", "text", "audio", "fusion"))
+        self.fp8_stacks = () if not self.fp8 else (("video", "text", "audio", "fusion") if name == "fp8-all" else ("video",))
+        # Weight gradients of the fp8 stacks: bf16 (the grouped 256-wide TN kernel, bias sums fused, no transposed e4m3 copies to produce) unless
+        # "fp8-wgrad8"/"fp8-all": e4m3 NT GEMMs of transposed quantised copies split over the token axis.  At config 5 / batch 16 the bf16 form wins
+        # since the 256-wide weight-gradient tile exists (profiles/r02_experiments.md).
+        self.fp8_wgrad8 = name in ("fp8-wgrad8", "fp8-all")
 
 
 class WeightCache:
@@ -333,19 +337,19 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         else:
             a = x_lp if x_lp is not None else _to_lp(pol, x)
             mean1 = rstd1 = None
-        a8 = ops.fp8_quantize(a, want_t=True)
+        a8 = ops.fp8_quantize(a, want_t=pol.fp8_wgrad8)
         qkv = ops.gemm_nt_fp8(a8, wqkv8, bias=bqkv)
         o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        o8 = ops.fp8_quantize(o, want_t=True)
+        o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8)
         y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
         if spec.pre_ln:
             x1 = y1
             _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
         else:
             x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
-        c8 = ops.fp8_quantize(c, want_t=True)
+        c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8)
         h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
-        h8 = ops.fp8_quantize(h, want_t=True)
+        h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8)
         y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
         if spec.pre_ln:
             x2, x2_lp = y2, None
@@ -356,8 +360,12 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         ctx.has = [p is not None for p in params]
         ctx.rows = a.shape[0]
         corr, o_soft = aux
+        if pol.fp8_wgrad8:
+            keep = (a8.qt, a8.scales, o8.qt, o8.scales, c8.qt, c8.scales, h8.qt, h8.scales)
+        else:                                    # the bf16 operands of the weight-gradient GEMMs (o is saved for attention anyway)
+            keep = (a, None, None, None, c, None, h, None)
         ctx.save_for_backward(x if spec.pre_ln else None, qkv, o, lse, corr, o_soft, y1, u, y2 if not spec.pre_ln else None, mean1, rstd1, mean2, rstd2, key_mask,
-                              a8.qt, a8.scales, o8.qt, o8.scales, c8.qt, c8.scales, h8.qt, h8.scales, *params)
+                              *keep, *params)
         if x2_lp is None:
             x2_lp = x2.new_empty(0)
         ctx.mark_non_differentiable(x2_lp)
@@ -373,7 +381,9 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         B, S, nh = spec.B, spec.S, spec.nheads
         H, F, M = nh * 64, w1.shape[0], ctx.rows
         wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
-        a8, o8, c8, h8 = (ops.Fp8(None, t, s, M, t.shape[0]) for t, s in ((a_t, a_s), (o_t, o_s), (c_t, c_s), (h_t, h_s)))
+        w8 = pol.fp8_wgrad8
+        if w8:
+            a8, o8, c8, h8 = (ops.Fp8(None, t, s, M, t.shape[0]) for t, s in ((a_t, a_s), (o_t, o_s), (c_t, c_s), (h_t, h_s)))
 
         def dgrad(dy8, w8, **kw):            # dY [M, N] x W [N, K] -> [M, K]: the NT GEMM against the transposed copy W^T [K, N_pad]
             return ops.gemm_nt(dy8.q, w8.qt[:, :w8.rows], a_dequant=dy8.dequant, b_dequant=w8.dequant, **kw)
@@ -385,9 +395,9 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
             dg2 = db2 = None
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
-        dy28 = ops.fp8_quantize(dy2_lp, want_t=True)
+        dy28 = ops.fp8_quantize(dy2_lp, want_t=w8)
         du = dgrad(dy28, w28, gelu_in=u, act=4)
-        du8 = ops.fp8_quantize(du, want_t=True)
+        du8 = ops.fp8_quantize(du, want_t=w8)
         if spec.pre_ln:
             dc = dgrad(du8, w18, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
@@ -395,19 +405,22 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         else:
             g1 = dgrad(du8, w18, resid=dy2, out_dtype=torch.float32)
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
-        dy18 = ops.fp8_quantize(dy1_lp, want_t=True)
+        dy18 = ops.fp8_quantize(dy1_lp, want_t=w8)
         do = dgrad(dy18, wo8)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        dqkv8 = ops.fp8_quantize(dqkv, want_t=True)
+        dqkv8 = ops.fp8_quantize(dqkv, want_t=w8)
         if spec.pre_ln:
             da = dgrad(dqkv8, wqkv8, out_dtype=torch.float32)
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON)
             _hint_set(g0, g0_lp)
         else:
             g0 = dgrad(dqkv8, wqkv8, resid=dy1, out_dtype=torch.float32)
-        dW2, dW1, dWo, dWqkv = ops.wgrad_fp8(dy28, h8), ops.wgrad_fp8(du8, c8), ops.wgrad_fp8(dy18, o8), ops.wgrad_fp8(dqkv8, a8)
-        dB2, dB1, dBo, dBqkv = ops.colsum(dy2_lp), ops.colsum(du), ops.colsum(dy1_lp), ops.colsum(dqkv)
+        if w8:
+            dW2, dW1, dWo, dWqkv = ops.wgrad_fp8(dy28, h8), ops.wgrad_fp8(du8, c8), ops.wgrad_fp8(dy18, o8), ops.wgrad_fp8(dqkv8, a8)
+            dB2, dB1, dBo, dBqkv = ops.colsum(dy2_lp), ops.colsum(du), ops.colsum(dy1_lp), ops.colsum(dqkv)
+        else:                                    # one grouped bf16 launch, bias sums fused (a_t / c_t / h_t hold the bf16 activations here)
+            (dWqkv, dBqkv), (dWo, dBo), (dW1, dB1), (dW2, dB2) = ops.gemm_tn_grouped([(dqkv, a_t), (dy1_lp, o), (du, c_t), (dy2_lp, h_t)], want_bias=True)
         grads = [dg1, db1, dWqkv[:H], dBqkv[:H], dWqkv[H:2 * H], dBqkv[H:2 * H], dWqkv[2 * H:], dBqkv[2 * H:], dWo, dBo, dg2, db2, dW1, dB1, dW2, dB2]
         grads = [g if has else None for g, has in zip(grads, ctx.has)]
         return (g0, None, None, None, None, *grads)
