@@ -81,6 +81,33 @@ def test_nt_schedule_mixes_tiles_only_when_the_last_round_is_short():
     assert h.tav_gemm_nt_schedule(C.byref(g), C.byref(t_), C.byref(r_), C.byref(tr_)) == -2     # M = 0: unsupported shape
 
 
+def test_grouped_wgrad_workspace_plan_is_host_arithmetic():
+    """tav_gemm_tn_grouped_ws_bytes: a 768-wide layer's four gradients at batch 32 (46848 rows, bf16) take the 256-wide tile with two token
+    splits -- two f32 slabs of every gradient plus the bias partials [2 splits][N2 / 256 tiles][N1]; small or f32 problems only need the
+    bias partials of the 128-wide tile rows; forcing flags change the plan."""
+    h = _lib.lib()
+    H, F = 768, 3072
+    shapes = [(3 * H, H), (H, H), (F, H), (H, F)]
+
+    def nbytes(rows, dtype=1, flags=0, bias=True):
+        probs = (_lib.GemmTNProblem * 4)()
+        for k, (n1, n2) in enumerate(shapes):
+            probs[k].A, probs[k].B, probs[k].out, probs[k].dbias = 1, 1, 1, (1 if bias else None)
+            probs[k].N1, probs[k].N2, probs[k].lda, probs[k].ldb = n1, n2, n1, n2
+        return h.tav_gemm_tn_grouped_ws_bytes(probs, 4, rows, dtype, flags)
+
+    elems = sum(a * b for a, b in shapes)
+    big_bias = sum(2 * ((n2 + 255) // 256) * n1 for n1, n2 in shapes)
+    small_bias = sum(((n2 + 127) // 128) * n1 for n1, n2 in shapes)
+    assert nbytes(32 * 1464) == 4 * (2 * elems + big_bias)
+    assert nbytes(32 * 1464, bias=False) == 4 * 2 * elems
+    assert nbytes(4 * 1464) == 4 * small_bias                     # too few rows for slabs to pay: 128-wide tiles, bias partials only
+    assert nbytes(32 * 1464, dtype=0) == 4 * small_bias           # f32 operands: 128-wide only
+    assert nbytes(32 * 1464, flags=2) == 4 * small_bias           # forced 128-wide
+    assert nbytes(4 * 1464, flags=1 | (3 << 8)) == 4 * (3 * elems + sum(3 * ((n2 + 255) // 256) * n1 for n1, n2 in shapes))
+    assert h.tav_gemm_tn_grouped_ws(None, 4, 100, 1, None, 0, 0, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtavhip.so")
