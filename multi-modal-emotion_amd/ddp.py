@@ -8,6 +8,8 @@ last gradient of a bucket has been accumulated, a side HIP stream waits on an ev
 all-reduce (average) and re-points the parameters' .grad at views of the reduced bucket (no copy back).  The main stream
 keeps running the backward of earlier layers meanwhile; `finish()` joins the side stream before clipping / the update.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -257,6 +259,9 @@ class SegmentedBackward:
         return self.final[s]
 
 
+_SKIP_REDUCE = os.environ.get("TAV_DDP_SKIP_REDUCE", "0") == "1"     # measurement knob: time the graph chain without the collective (results unreduced)
+
+
 class GraphedStep:
     """The data-parallel training step of bench.py (N > 1): S+1 hipGraphs with the bucket all-reduces issued eagerly between them on the
     reducer stream (see the block comment above).  `forward_loss()` must run PreFormer + model + criterion on static input tensors."""
@@ -310,7 +315,7 @@ class GraphedStep:
 
     def _reduce(self, flat):
         red = self.red
-        if not red._active:
+        if not red._active or _SKIP_REDUCE:
             return
         buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
         dist.all_reduce(buf, op=dist.ReduceOp.AVG if red._avg else dist.ReduceOp.SUM, group=red.pg)
