@@ -104,7 +104,7 @@ if "tng" in what:         # the four weight gradients of one encoder layer in on
         print(f"[{tag}] gemm_tn_grouped {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
         lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=False), iters=20, reps=5)
         print(f"[{tag}]   (no bias sums)  {name:7s} layer M={M:6d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
-        for fl_name, flg in (("128-wide tiles", 2), ("256-wide x1", 1 | (1 << 8)), ("256-wide x2", 1 | (2 << 8)), ("256-wide x3", 1 | (3 << 8))):
+        for fl_name, flg in (("128-wide tiles", 2), ("256-wide x1", 1 | (1 << 8)), ("256-wide x2", 1 | (2 << 8)), ("256-wide x3", 1 | (3 << 8)), ("256-wide x7", 1 | (7 << 8))):
             if (flg >> 8) > 1 and M // (flg >> 8) < 64:
                 continue
             lo, med = timeit(lambda: ops.gemm_tn_grouped(pairs, want_bias=True, flags=flg), iters=20, reps=5)
