@@ -147,6 +147,27 @@ TAV_DEV void row_frags_gload(uint4* f, const char* base, long ld_bytes, int r, i
 }
 
 // ================================================================================================= forward
+// ablation switches for the forward kernel (tools/ab_build.sh; timing experiments only, results are wrong with any of them set)
+#ifdef TAV_ABL_ATT_NOMFMA
+#define ATT_FWD_MMA(a, b, c) do { (c)[0] += __uint_as_float((a).x ^ (b).x); } while (0)
+#else
+#define ATT_FWD_MMA(a, b, c) mma16<T>(a, b, c)
+#endif
+#ifdef TAV_ABL_ATT_NOEXP
+#define ATT_FWD_EXP2(x) ((x) * 0.5f)
+#else
+#define ATT_FWD_EXP2(x) fast_exp2(x)
+#endif
+#ifdef TAV_ABL_ATT_NOGLOAD
+constexpr bool ATT_ABL_NOGLOAD = true;
+#else
+constexpr bool ATT_ABL_NOGLOAD = false;
+#endif
+#ifdef TAV_ABL_ATT_NOBAR
+constexpr bool ATT_ABL_NOBAR = true;
+#else
+constexpr bool ATT_ABL_NOBAR = false;
+#endif
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     using H = HD<T>;
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 
     for (int t = 0; t < nkt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nkt) gload(t + 1);
+        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) gload(t + 1);
         const char* Krow = smem + cur * BUF_B;
         const char* Vnat = Krow + KROW_B;
         const float* kadd = reinterpret_cast<const float*>(Vnat + VNAT_B);
@@ -249,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
             for (int s = 0; s < NSD; ++s)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    mma16<T>(kfr[kt][s], qf[0][s], sacc[kt][0]);
-                    mma16<T>(kfr[kt][s], qf[1][s], sacc[kt][1]);
+                    ATT_FWD_MMA(kfr[kt][s], qf[0][s], sacc[kt][0]);
+                    ATT_FWD_MMA(kfr[kt][s], qf[1][s], sacc[kt][1]);
                 }
         } else {
 #pragma unroll
@@ -258,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const uint4 a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
-                    mma16<T>(a, qf[0][s], sacc[kt][0]);
-                    mma16<T>(a, qf[1][s], sacc[kt][1]);
+                    ATT_FWD_MMA(a, qf[0][s], sacc[kt][0]);
+                    ATT_FWD_MMA(a, qf[1][s], sacc[kt][1]);
                 }
         }
         // running max per query (= per lane i, both q tiles), then p = exp2(s*c2 + kadd - m).  The per-key additive term is zero
@@ -282,13 +303,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx[qt]));
-                alpha[qt] = fast_exp2(m_run[qt] - m_new);
+                alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
                 moved |= m_new > m_run[qt];
                 m_run[qt] = m_new;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] - m_new);
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(sacc[kt][qt][r] - m_new);
             }
         } else {
 #pragma unroll
@@ -298,13 +319,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
                 for (int kt = 1; kt < 4; ++kt)
                     mx = fmaxf(fmaxf(mx, sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
                 const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx) * c2);
-                alpha[qt] = fast_exp2(m_run[qt] - m_new);
+                alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
                 moved |= m_new > m_run[qt];
                 m_run[qt] = m_new;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(__builtin_fmaf(sacc[kt][qt][r], c2, -m_new));
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(__builtin_fmaf(sacc[kt][qt][r], c2, -m_new));
             }
         }
         if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
@@ -326,15 +347,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
                 tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
                 pb[qt] = acc_to_kfrag<T>(tl);
             }
-            mma16<T>(ones, pb[0], lacc[0]);
-            mma16<T>(ones, pb[1], lacc[1]);
+            ATT_FWD_MMA(ones, pb[0], lacc[0]);
+            ATT_FWD_MMA(ones, pb[1], lacc[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint4 a;
                 if constexpr (HOIST) a = vfr[ks][dt];
                 else a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
-                mma16<T>(a, pb[0], oacc[dt][0]);
-                mma16<T>(a, pb[1], oacc[dt][1]);
+                ATT_FWD_MMA(a, pb[0], oacc[dt][0]);
+                ATT_FWD_MMA(a, pb[1], oacc[dt][1]);
             }
         }
         if (MODE == 2) {   // c[d] += sum_key mask[key] * V[key][d]; thread -> (d = tid & 63, 16 keys of this tile)
@@ -345,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
                 corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
             }
         }
-        if (t + 1 < nkt) lstore(t + 1, cur ^ 1);
-        __syncthreads();
+        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) lstore(t + 1, cur ^ 1);
+        if (!ATT_ABL_NOBAR) __syncthreads();
     }
 
     if (MODE == 2) {
