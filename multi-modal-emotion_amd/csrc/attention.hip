@@ -24,6 +24,10 @@
 #define TAV_HOIST_FWD 1
 #endif
 // (the same hoisting in the two backward kernels measured -1 %: not built)
+// forward kernel, bf16: K / V tiles staged by LDS-DMA (global_load_lds_dwordx4) into swizzled ROW images instead of registers + ds_write
+#ifndef TAV_ATT_DMA
+#define TAV_ATT_DMA 1      // 0: register staging (322 us at S = 1464, batch 32), 1: DMA one tile ahead (300-312), 2: two tiles ahead, unmasked mode (315)
+#endif
 #ifndef TAV_DKDV_BQ
 #define TAV_DKDV_BQ 64       // bf16 query-tile height of the dK/dV kernel (32 or 64)
 #endif
@@ -173,10 +177,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
-    constexpr int KROW_B = BKV * H::ROWB, VNAT_B = BKV * H::PITCH_N;
+    // bf16: both tiles live in the swizzled row image (H::row_off), which is linear per 8 rows -- one DMA instruction fills 8 rows x 8
+    // slots, the XOR applied to the SOURCE chunk a lane fetches -- and serves the row reads (K) as well as the transposed reads (V,
+    // frag_tr_rowimg).  An ablation priced the register staging (global -> VGPR -> ds_write, address arithmetic per tile) at 25 % of the
+    // kernel (profiles/r02_experiments.md).  f32 keeps the register path and the padded natural V image.
+    constexpr bool DMA = (ES == 2) && TAV_ATT_DMA;
+    constexpr int KROW_B = BKV * H::ROWB, VNAT_B = DMA ? BKV * H::ROWB : BKV * H::PITCH_N;
     constexpr int BUF_B = KROW_B + VNAT_B + 2 * BKV * 4;
+    // TAV_ATT_DMA = 2: three buffers, the DMA runs TWO tiles ahead in the unmasked mode (the mask modes' per-tile mask load shares vmcnt).
+    // Measured no faster than one tile ahead: the staging latency is not what this kernel waits for (profiles/r02_experiments.md).
+    constexpr int NBUF = (DMA && MODE == 0 && TAV_ATT_DMA >= 2) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem + 2 * BUF_B);   // [4][64] + [64]
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF_B);   // [4][64] + [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int head = blockIdx.y, b = blockIdx.z, S = p.S;
@@ -213,9 +225,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
     tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
     const unsigned kstep_b = (unsigned)(BKV * p.ld_k * ES), vstep_b = (unsigned)(BKV * p.ld_v * ES);
+    // DMA geometry: wave w fills rows [16w, 16w + 16) of both images, 8 rows per instruction; lane -> (row, slot), source chunk = slot ^ swizzle
+    unsigned dk_off[2], dk_max[2], dv_off[2], dv_max[2];
+    unsigned lds_k = 0, lds_v = 0;
+    if constexpr (DMA) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+            const int ch = slot ^ (((row >> 1) & 3) << 1);
+            dk_off[j] = (unsigned)(row * p.ld_k * ES + ch * 16); dk_max[j] = (unsigned)((S - 1) * p.ld_k * ES + ch * 16);
+            dv_off[j] = (unsigned)(row * p.ld_v * ES + ch * 16); dv_max[j] = (unsigned)((S - 1) * p.ld_v * ES + ch * 16);
+        }
+        lds_k = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 16 * H::ROWB);
+        lds_v = lds_k + KROW_B;
+    }
+    auto dma = [&](int t, int buf) {                       // rows past S are clamped to row S-1 (finite data; their scores are -inf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned ok = dk_off[j] + t * kstep_b; ok = ok < dk_max[j] ? ok : dk_max[j];
+            unsigned ov = dv_off[j] + t * vstep_b; ov = ov < dv_max[j] ? ov : dv_max[j];
+            glds16_s(Kb, ok, lds_k + buf * BUF_B + j * 1024);
+            glds16_s(Vb, ov, lds_v + buf * BUF_B + j * 1024);
+        }
+    };
     auto gload = [&](int t) {
-        tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
-        tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        if constexpr (!DMA) {
+            tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
+            tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        }
         if (MODE != 0 && tid < BKV) {
             int key = t * BKV + tid;
             key = key < S ? key : S - 1;
@@ -224,8 +261,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     };
     auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
-        tile_lstore_row<T, BKV>(rk, base, tid);
-        tile_lstore_nat<T, BKV>(rv, base + KROW_B, tid);
+        if constexpr (!DMA) {
+            tile_lstore_row<T, BKV>(rk, base, tid);
+            tile_lstore_nat<T, BKV>(rv, base + KROW_B, tid);
+        }
         if (tid < BKV) {
             const bool ok = t * BKV + tid < S;
             float* f = reinterpret_cast<float*>(base + KROW_B + VNAT_B);
@@ -233,15 +272,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
             f[BKV + tid] = (MODE == 2 && ok) ? r_mask : 0.f;
         }
     };
+    if constexpr (DMA) { dma(0, 0); if (NBUF == 3 && nkt > 1) dma(1, 1); }
     gload(0); lstore(0, 0);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int s = 0; s < NSD; ++s) settle(qf[qt][s]);
+    if constexpr (DMA) {
+        if (NBUF == 3 && nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile 0 landed, tile 1 (4 younger instructions) may fly
+        else wait_vmcnt0();
+    }
     __syncthreads();
 
     for (int t = 0; t < nkt; ++t) {
-        const int cur = t & 1;
+        const int cur = NBUF == 3 ? t % 3 : (t & 1);
+        const int nxt = NBUF == 3 ? (t + 1) % 3 : (cur ^ 1);
+        if constexpr (DMA) {                                // (the refilled buffer was last read in iteration t-1, behind a barrier)
+            if (NBUF == 3) { if (t + 2 < nkt && !ATT_ABL_NOGLOAD) dma(t + 2, (t + 2) % 3); }
+            else if (t + 1 < nkt && !ATT_ABL_NOGLOAD) dma(t + 1, nxt);
+        }
         if (t + 1 < nkt && !ATT_ABL_NOGLOAD) gload(t + 1);
         const char* Krow = smem + cur * BUF_B;
         const char* Vnat = Krow + KROW_B;
@@ -264,7 +313,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) vfr[ks][dt] = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                for (int dt = 0; dt < 4; ++dt) {
+                    if constexpr (DMA) vfr[ks][dt] = frag_tr_rowimg(Vnat, ks * KSTEP, dt, lane);
+                    else vfr[ks][dt] = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
+                }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < NSD; ++s)
@@ -353,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
             for (int dt = 0; dt < 4; ++dt) {
                 uint4 a;
                 if constexpr (HOIST) a = vfr[ks][dt];
+                else if constexpr (DMA) a = frag_tr_rowimg(Vnat, ks * KSTEP, dt, lane);
                 else a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
                 ATT_FWD_MMA(a, pb[0], oacc[dt][0]);
                 ATT_FWD_MMA(a, pb[1], oacc[dt][1]);
@@ -363,10 +416,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll 4
             for (int kk = 0; kk < 16; ++kk) {
                 const int key = kq * 16 + kk;
-                corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
+                if constexpr (DMA) corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + H::row_off(key, d >> 3)) + (d & 7));
+                else corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
             }
         }
-        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) lstore(t + 1, cur ^ 1);
+        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) lstore(t + 1, nxt);
+        if constexpr (DMA) {                                // tile t+1 must have landed; tile t+2's four instructions may still fly
+            if (NBUF == 3 && t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else wait_vmcnt0();
+        }
         if (!ATT_ABL_NOBAR) __syncthreads();
     }
 
@@ -769,8 +827,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     }
 }
 
-template <typename T> constexpr size_t fwd_lds() {
-    return 2 * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
+template <typename T> constexpr size_t fwd_lds() {           // (bf16: room for the three-buffer DMA ring of the unmasked forward)
+    return (HD<T>::ES == 2 ? 3 : 2) * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
 }
 template <typename T> constexpr size_t dkdv_lds() {
     return 2 * (2 * dkdv_bq<T>() * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * dkdv_bq<T>() * HD<T>::PITCH_N) + 2 * dkdv_bq<T>() * 4) + (256 + 64) * 4;
