@@ -21,7 +21,7 @@
 
 // A/B switches (tools/ab_build.sh): issue all LDS fragment reads of a tile ahead of its first MFMA
 #ifndef TAV_HOIST_FWD
-#define TAV_HOIST_FWD 1
+#define TAV_HOIST_FWD 0      // 1 needs 204 VGPRs (two waves per SIMD); without it the kernel fits three (165) and is 4-9 % faster
 #endif
 // (the same hoisting in the two backward kernels measured -1 %: not built)
 // forward kernel, bf16: K / V tiles staged by LDS-DMA (global_load_lds_dwordx4) into swizzled ROW images instead of registers + ds_write
@@ -172,8 +172,11 @@ constexpr bool ATT_ABL_NOBAR = true;
 #else
 constexpr bool ATT_ABL_NOBAR = false;
 #endif
+#ifndef TAV_ATT_FWD_OCC
+#define TAV_ATT_FWD_OCC 3      // waves per SIMD the forward kernel is compiled for (register budget 512 / OCC; 4 spills and halves the speed)
+#endif
 template <typename T, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
@@ -489,8 +492,15 @@ __global__ void attn_bwd_delta_kernel(const AttnP p) {
 // f32 (register budget)
 template <typename T> constexpr int dkdv_bq() { return sizeof(T) == 2 ? TAV_DKDV_BQ : 32; }
 
+// (waves per SIMD the backward kernels are compiled for: at 3 both spill -- 48..256 B of scratch -- which halved the forward's speed when tried there)
+#ifndef TAV_ATT_DKDV_OCC
+#define TAV_ATT_DKDV_OCC 2
+#endif
+#ifndef TAV_ATT_DQ_OCC
+#define TAV_ATT_DQ_OCC 2
+#endif
 template <typename T, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T>(), NQT = BQ / 16;
     constexpr int NCH = BQ * H::ROWCH / 256;
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnP p) {
 
 // ================================================================================================= backward: dQ
 template <typename T, int MODE>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void attn_bwd_dq_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
@@ -828,7 +838,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 }
 
 template <typename T> constexpr size_t fwd_lds() {           // (bf16: room for the three-buffer DMA ring of the unmasked forward)
-    return (HD<T>::ES == 2 ? 3 : 2) * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
+    return ((HD<T>::ES == 2 && TAV_ATT_DMA >= 2) ? 3 : 2) * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
 }
 template <typename T> constexpr size_t dkdv_lds() {
     return 2 * (2 * dkdv_bq<T>() * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * dkdv_bq<T>() * HD<T>::PITCH_N) + 2 * dkdv_bq<T>() * 4) + (256 + 64) * 4;
