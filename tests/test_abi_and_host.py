@@ -81,6 +81,38 @@ def test_nt_schedule_mixes_tiles_only_when_the_last_round_is_short():
     assert h.tav_gemm_nt_schedule(C.byref(g), C.byref(t_), C.byref(r_), C.byref(tr_)) == -2     # M = 0: unsupported shape
 
 
+def test_nt_schedule_invariants_over_random_shapes():
+    """Whatever the shape, the plan is well formed: the first launch covers a positive number of rows <= M; a second launch only follows whole
+    256-row tiles of the 256 x 256 tile, takes a 128-wide tile, and never appears for f32 operands, batched calls or forced tiles."""
+    import random
+    h = _lib.lib()
+    rnd = random.Random(1234)
+    for _ in range(400):
+        M = rnd.choice([1, 7, 128, 255, 256, 257, 1000, 4096, 11712, 23424, 46848, 46885, 255968]) + rnd.randrange(0, 3)
+        N = 4 * rnd.randrange(1, 1025)
+        K = 64 * rnd.randrange(1, 65)
+        in_dt = rnd.choice([0, 1])
+        out_dt = 0 if in_dt == 0 else rnd.choice([0, 1])
+        g = _lib.GemmNTArgs()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, K, K, N
+        g.in_dtype, g.out_dtype, g.nzb, g.nzg = in_dt, out_dt, rnd.choice([1, 1, 1, 3]), 1
+        g.tile_m_hint = rnd.choice([0, 0, 0, 2, 3, 4, 16, 17])
+        g.act = rnd.choice([0, 0, 1, 3])
+        if rnd.random() < 0.3:
+            g.resid = 1
+        t, r, tr = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = h.tav_gemm_nt_schedule(C.byref(g), C.byref(t), C.byref(r), C.byref(tr))
+        assert rc == 0, (rc, M, N, K)
+        assert t.value in (2, 3, 4, 8, 16) and 0 < r.value <= M
+        if tr.value:
+            assert t.value == 16 and r.value % 256 == 0 and r.value < M and tr.value in (2, 3, 4)
+            assert in_dt == 1 and g.nzb == 1 and g.tile_m_hint == 0
+        else:
+            assert r.value == M
+        if in_dt == 0:
+            assert t.value in (2, 3, 4)
+
+
 def test_grouped_wgrad_workspace_plan_is_host_arithmetic():
     """tav_gemm_tn_grouped_ws_bytes: a 768-wide layer's four gradients at batch 32 (46848 rows, bf16) take the 256-wide tile with two token
     splits -- two f32 slabs of every gradient plus the bias partials [2 splits][N2 / 256 tiles][N1]; small or f32 problems only need the
