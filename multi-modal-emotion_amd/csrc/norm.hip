@@ -114,22 +114,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
     }
 }
 
-// one workgroup per 64 columns: 4 row-groups x 64 columns, fixed summation order (deterministic)
-__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W,
-                                                               int accumulate) {
-    __shared__ float red[16][64][2];
-    const int l = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
-    float g = 0.f, b = 0.f;
-    if (c < W)
-        for (int k = rg; k < nblocks; k += 16) { g += partials[((long)k * 2 + 0) * W + c]; b += partials[((long)k * 2 + 1) * W + c]; }
-    red[rg][l][0] = g; red[rg][l][1] = b;
-    __syncthreads();
-    if (rg == 0 && c < W) {
-        g = 0.f; b = 0.f;
+// one workgroup per 16 columns: 4 column quads (16-B loads) x 64 row groups, fixed summation order (deterministic).  (12 workgroups of 64
+// columns with 4-byte loads took 10 us for 512 partial rows -- 106 launches per step.)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta, int nblocks, int W,
+                                                              int accumulate) {
+    __shared__ float red[64][16][2];
+    const int cq = threadIdx.x & 3, rg = threadIdx.x >> 2, c = blockIdx.x * 16 + 4 * cq;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, b = g;
+    if (c < W) {
+#pragma unroll 4
+        for (int k = rg; k < nblocks; k += 64) { g += ld4(partials + ((long)k * 2 + 0) * W + c); b += ld4(partials + ((long)k * 2 + 1) * W + c); }
+    }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { g += red[k][l][0]; b += red[k][l][1]; }
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + g : g;
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+    for (int e = 0; e < 4; ++e) { red[rg][4 * cq + e][0] = g[e]; red[rg][4 * cq + e][1] = b[e]; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int l = threadIdx.x, cc = blockIdx.x * 16 + l;
+        if (cc < W) {
+            float sg = 0.f, sb = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) { sg += red[k][l][0]; sb += red[k][l][1]; }
+            if (dgamma) dgamma[cc] = accumulate ? dgamma[cc] + sg : sg;
+            if (dbeta) dbeta[cc] = accumulate ? dbeta[cc] + sb : sb;
+        }
     }
 }
 
@@ -321,7 +328,7 @@ extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
     int e = (int)hipGetLastError();
     if (e) return e;
     if (p.partials) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 64)), dim3(1024), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 16)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
                            a->accumulate_params);
         e = (int)hipGetLastError();
     }
