@@ -8,7 +8,7 @@
 namespace tav {
 
 constexpr int C0_TT = 128;     // output steps per workgroup (conv0 forward): enough stores to amortise the weight loads of the prologue
-constexpr int C0_BT = 256;     // output steps per workgroup of the conv0 weight gradient (4 time groups x 64 steps)
+constexpr int C0_BT = 512;     // output steps per workgroup of the conv0 weight gradient (4 time groups x 128 steps): half the partial blocks of 256 for the final reduce
 constexpr int C0_MAXK = 16;
 
 // y[b][t][c] = sum_j x[b][s*t + j] * w[c][j] + bias[c];  thread owns 4 consecutive channels {4q .. 4q+3, q = tid, tid + 256, ...} of the output
