@@ -8,8 +8,11 @@
 // Replaces the ATen/cuBLAS call sites listed in SURVEY.md §2.1 (reference utils/TAVFormer.py:348-350,393-439;
 // HF roberta/wav2vec2/videomae linears; wav2vec2 conv stack).
 //
-// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles of 16x16),
-// K-tile = 128 bytes per row (64 bf16 / 32 f32), register-staged global->LDS double buffer, one barrier per K-tile.
+// NT tiles: 64/96/128 x 128 (4 waves as 2x2, 2 workgroups per CU) or 256 x 256 (8 waves as 4x2, each a 64 x 128 block of 16x16 MFMA tiles, one
+// workgroup per CU), K-tile = 128 bytes per row (64 bf16 / 32 f32 / 128 e4m3), staged by LDS-DMA (global_load_lds_dwordx4 from inline asm) into a
+// 2- to 4-deep ring with the next tile's DMA pieces issued between the MFMA groups, one barrier per K-tile.  The host picks the tile -- or a mix of
+// both over disjoint row ranges -- per call from a fitted cost model (nt_pick_tile, tav_gemm_nt_schedule) and the epilogue flavour (EPI) from the
+// arguments.  TN tiles: 128 x 128 (4 waves) or 256 x 256 (8 waves, token axis split into f32 slabs), 64-token K-tiles, transposed fragment reads.
 // LDS image of the NT kernel: [row][8 chunks of 16 B], chunk index XOR-swizzled with (row>>1)&7 so that the
 // ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group) are bank-conflict free.
 #include <stdlib.h>
