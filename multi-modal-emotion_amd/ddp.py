@@ -28,6 +28,8 @@ class BucketedAllReduce:
         self._pending = {}
         self._streams = {}                           # bucket -> streams its gradients were written on (the branches run on their own)
         self._works = []
+        self._complete = set()                       # buckets whose gradients have all arrived (hook mode)
+        self._next = 0                               # hook mode launches buckets STRICTLY in index order: next one to go
         self._manual = False
         self._cuda = self.params[0].is_cuda
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"    # RCCL has AVG; gloo sums then scales
@@ -48,8 +50,9 @@ class BucketedAllReduce:
             buckets.append(cur)
         self.buckets = []
         for plist in buckets:
-            n = sum(p.numel() for p in plist)
+            n = sum(p.numel() for p in plist) + len(plist)         # + one "used" flag per parameter (see _launch)
             flat = torch.empty(n, dtype=torch.float32, device=plist[0].device)
+            flat[n - len(plist):].fill_(1.0)                        # (manual / graph mode never rewrites the flags: every gradient is required there)
             self.buckets.append((plist, flat))
         self._bucket_of = {p: i for i, (plist, _) in enumerate(self.buckets) for p in plist}
 
@@ -72,7 +75,14 @@ class BucketedAllReduce:
             # gradient of this bucket (text / audio / video branches accumulate on their own streams, runtime.branch_streams)
             self._streams.setdefault(i, set()).add(torch.cuda.current_stream())
         if not left:
-            self._launch(i)
+            # Collectives must be issued in the SAME order on every rank.  A rank that misses a gradient of bucket 0 would otherwise
+            # launch 1, 2, ... from its hooks and 0 only in finish(), against 0, 1, 2 on the other ranks (differently sized
+            # all-reduces paired up: a hang or mixed buckets).  So bucket i goes only once 0 .. i-1 have gone; whatever is still
+            # held back when the backward ends is launched by finish(), again in index order.
+            self._complete.add(i)
+            while self._next in self._complete:
+                self._launch(self._next)
+                self._next += 1
 
     def _launch(self, i):
         plist, flat = self.buckets[i]
@@ -88,6 +98,7 @@ class BucketedAllReduce:
         with ctx, torch.no_grad():
             off = 0
             views = []
+            missing = [p.grad is None for p in plist]
             for p in plist:
                 n = p.numel()
                 v = flat[off:off + n].view_as(p)
@@ -97,11 +108,18 @@ class BucketedAllReduce:
                     v.copy_(p.grad)
                 views.append(v)
                 off += n
+            # tail of the bucket: one "this rank produced a gradient" flag per parameter, reduced with the data.  A parameter whose flag
+            # is zero on EVERY rank was used nowhere this step and keeps .grad = None (as torch DDP and the single-GPU step leave it:
+            # the optimizer must not decay it); the flags are read back only by a rank that misses a gradient itself.
+            flat[off:].fill_(1.0)
+            for j, m in enumerate(missing):
+                if m:
+                    flat[off + j].zero_()
             buf = flat if self.reduce_dtype is None else flat.to(self.reduce_dtype)
             if self._cuda:
                 buf.record_stream(self.side)
             work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append((work, i, buf, views))
+            self._works.append((work, i, buf, views, any(missing)))
 
     def finish(self):
         """Join all outstanding reductions; afterwards every p.grad holds the mean over ranks."""
@@ -118,12 +136,10 @@ class BucketedAllReduce:
             # Buckets not launched by the hooks: some parameter received no gradient on this rank this step.  Every rank must still
             # issue the same collectives in the same order, so ALL remaining buckets are reduced, in index order, with zeros in the
             # slots of the missing gradients (their .grad then becomes the mean over the ranks that did produce one).
-            launched = {i for _, i, _, _ in self._works}
-            for i in range(len(self.buckets)):
-                if i not in launched:
-                    self._launch(i)
+            for i in range(self._next, len(self.buckets)):
+                self._launch(i)
         import contextlib
-        for work, i, buf, views in self._works:
+        for work, i, buf, views, any_missing in self._works:
             plist, flat = self.buckets[i]
             with (torch.cuda.stream(self.side) if self._cuda else contextlib.nullcontext()), torch.no_grad():
                 work.wait()                          # side stream (not the main one) waits for the collective
@@ -131,11 +147,18 @@ class BucketedAllReduce:
                     flat.copy_(buf)
                 if not self._avg:
                     flat.mul_(1.0 / self.world)
-            for p, v in zip(plist, views):
-                p.grad = v
+            used = None
+            if any_missing:                          # (a host read, only on a rank and step that missed a gradient)
+                if self._cuda:
+                    self.side.synchronize()
+                used = (flat[flat.numel() - len(plist):] > 0).tolist()
+            for j, (p, v) in enumerate(zip(plist, views)):
+                p.grad = v if used is None or used[j] or p.grad is not None else None
         self._works = []
         self._pending = {}
         self._streams = {}
+        self._complete = set()
+        self._next = 0
         if self._cuda:
             torch.cuda.current_stream().wait_stream(self.side)
 
@@ -148,6 +171,7 @@ class BucketedAllReduce:
         if on:
             self.buckets = None
             self._pending, self._works, self._ready = {}, [], []
+            self._complete, self._next = set(), 0
             if bucket_mb is not None:
                 self.bucket_bytes = int(bucket_mb * 2 ** 20)
 
@@ -264,22 +288,32 @@ _SKIP_REDUCE = os.environ.get("TAV_DDP_SKIP_REDUCE", "0") == "1"     # measureme
 
 class GraphedStep:
     """The data-parallel training step of bench.py (N > 1): S+1 hipGraphs with the bucket all-reduces issued eagerly between them on the
-    reducer stream (see the block comment above).  `forward_loss()` must run PreFormer + model + criterion on static input tensors."""
+    reducer stream (see the block comment above).  `forward_loss()` must run PreFormer + model + criterion on static input tensors.
+    `use_graphs=False` runs the same chain eagerly (forward, segments, packs, collectives in the same order) on any device: that is what
+    the 2-rank gloo test on the CPU exercises, and a debugging aid on the GPU."""
 
-    def __init__(self, stepper, forward_loss, stream, segments=4):
+    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None):
         from . import runtime
         red = stepper.reducer
         self.red, self.stepper, self.stream = red, stepper, stream
         red.set_manual(True)
         self.side = red.side
+        self.use_graphs = bool(use_graphs)
+        self._forward_loss = forward_loss
         k = max(1, int(segments))
-        fr = tuple(runtime.CUT_FRACTIONS) if k == 4 else tuple((j + 0.25) / k for j in range(k - 1)) if k > 1 else ()
+        if fractions is None:
+            fractions = tuple(runtime.CUT_FRACTIONS) if k == 4 else tuple((j + 0.25) / k for j in range(k - 1)) if k > 1 else ()
+        self.fractions = tuple(fractions)
         self.graphs, self.flats = [], []
+        self._plan = None                           # [(parameter names / sizes per bucket)] fixed by the first pass, checked on later eager ones
+        if not self.use_graphs:
+            self.loss = None
+            return
         # capture_error_mode "thread_local": the process group's watchdog thread polls its work events (hipEventQuery) at any time;
         # under the default global mode such a call from ANOTHER thread invalidates the capture (hipErrorStreamCaptureUnsupported)
         mode = dict(capture_error_mode="thread_local")
         g0 = torch.cuda.CUDAGraph()
-        runtime.begin_cuts(fr)
+        runtime.begin_cuts(self.fractions)
         with torch.cuda.graph(g0, stream=stream, **mode):
             self.loss = forward_loss()
             self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
@@ -293,16 +327,29 @@ class GraphedStep:
         self.gu = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool(), **mode):
             stepper.update()
-        red.buckets = [(plist, flat) for plist, flat in self.flats]          # hook mode, if switched back on, reuses these buckets
+        self._adopt_buckets()
+
+    def _adopt_buckets(self):
+        red = self.red
+        red.buckets = [(plist, flat) for plist, flat in self.flats if plist]  # hook mode, if switched back on, reuses these buckets
         red._bucket_of = {p: i for i, (plist, _) in enumerate(red.buckets) for p in plist}
         red._pending, red._streams, red._works = {}, {}, []
 
     def _run_and_pack(self, s):
         plist = [p for p in self.seg.run(s) if p.grad is not None]
+        if not plist:                                # a segment that finalises no parameter (shallow stack, few cuts): nothing to ship
+            self.flats.append(([], None))
+            return
         n = sum(p.numel() for p in plist)
+        reuse = self.flats[s][1] if len(self.flats) > s and self.flats[s][1] is not None else None     # (eager mode: keep the buffers)
         # allocated inside the capture, i.e. from the graphs' private pool: the reference kept in self.flats pins it for good, and
-        # the reducer / RCCL streams only ever touch it between two replays
-        flat = torch.empty(n, dtype=torch.float32, device=plist[0].device)
+        # the reducer / RCCL streams only ever touch it between two replays.  (+ the reducer's per-parameter "used" flags, all ones:
+        # in this mode every bucketed parameter must produce a gradient every step)
+        if reuse is not None and reuse.numel() == n + len(plist):
+            flat = reuse
+        else:
+            flat = torch.empty(n + len(plist), dtype=torch.float32, device=plist[0].device)
+            flat[n:].fill_(1.0)
         views, off = [], 0
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
@@ -311,11 +358,19 @@ class GraphedStep:
             torch._foreach_copy_(views, [p.grad for p in plist])
         for p, v in zip(plist, views):
             p.grad = v
-        self.flats.append((plist, flat))
+        if len(self.flats) > s:
+            self.flats[s] = (plist, flat)
+        else:
+            self.flats.append((plist, flat))
+
+    def bucket_signature(self):
+        """[(number of parameters, total elements)] per bucket: must be identical on every rank (each rank derives its buckets from
+        its own autograd graph; tests and bench.py compare this across ranks before the first collective)."""
+        return [(len(pl), int(sum(p.numel() for p in pl))) for pl, _ in self.flats]
 
     def _reduce(self, flat):
         red = self.red
-        if not red._active or _SKIP_REDUCE:
+        if flat is None or not red._active or _SKIP_REDUCE:
             return
         buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
         dist.all_reduce(buf, op=dist.ReduceOp.AVG if red._avg else dist.ReduceOp.SUM, group=red.pg)
@@ -325,6 +380,8 @@ class GraphedStep:
             flat.mul_(1.0 / red.world)
 
     def run(self):
+        if not self.use_graphs:
+            return self._run_eager()
         main = torch.cuda.current_stream()
         for g, (_, flat) in zip(self.graphs, self.flats):
             g.replay()
@@ -335,7 +392,38 @@ class GraphedStep:
         self.gu.replay()
         return self.loss
 
+    def _run_eager(self):
+        """The same chain without capture: forward + loss, then per segment {differentiate, pack bucket s, all-reduce bucket s}, then
+        clip + AdamW.  On the GPU the collective of bucket s goes to the reducer stream exactly as in run()."""
+        from . import runtime
+        cuda = self.side is not None
+        for p in self.red.params:
+            p.grad = None
+        runtime.begin_cuts(self.fractions)
+        self.loss = self._forward_loss()
+        self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
+        for s in range(self.seg.nseg):
+            self._run_and_pack(s)
+            flat = self.flats[s][1]
+            if cuda:
+                self.side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self._reduce(flat)
+            else:
+                self._reduce(flat)
+        if cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+        sig = self.bucket_signature()
+        if self._plan is None:
+            self._plan = sig
+            self._adopt_buckets()
+        elif sig != self._plan:
+            raise RuntimeError(f"data-parallel bucket plan changed between steps: {self._plan} -> {sig}")
+        self.stepper.update()
+        return self.loss
+
     def describe(self):
-        sizes = ", ".join(f"{flat.numel() * 4 / 2 ** 20:.0f}" for _, flat in self.flats)
-        return (f"{len(self.graphs)} hipGraphs (forward + backward cut into {self.seg.nseg} segments) + optimizer graph; bucket s all-reduced (RCCL, eager, "
-                f"side stream) while graph s+1 runs; buckets [{sizes}] MiB")
+        sizes = ", ".join(f"{(flat.numel() * 4 / 2 ** 20) if flat is not None else 0:.0f}" for _, flat in self.flats)
+        how = f"{len(self.graphs)} hipGraphs" if self.use_graphs else "eager chain"
+        return (f"{how} (forward + backward cut into {self.seg.nseg} segments) + optimizer {'graph' if self.use_graphs else 'call'}; bucket s all-reduced "
+                f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; buckets [{sizes}] MiB")

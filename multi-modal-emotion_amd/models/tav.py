@@ -80,7 +80,7 @@ class PreFormer(nn.Module):
             lens = attention_mask.to(dev).sum(-1).to(torch.float32)                         # frames that are not padding, per row
         else:
             lens = torch.full((B,), float(T), device=dev)
-        eps = torch.rand(B, device=dev)
+        eps = torch.rand(1, device=dev).expand(B)                                               # ONE epsilon per call, as _compute_mask_indices draws it
         n = torch.clamp((mask_prob * lens / mask_len + eps).floor(), min=float(min_masks))
         n = torch.minimum(n, torch.clamp(((lens - (mask_len - 1)) / 1.0).floor(), min=0.0))  # never more spans than start positions
         n = torch.minimum(n, torch.full_like(n, float(T // mask_len)))

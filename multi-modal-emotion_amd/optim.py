@@ -11,6 +11,7 @@ from ._lib import check, lib, ptr, stream
 
 class _PtrTable:
     """Pinned host staging + device array of int64 (pointers / sizes), refreshed with an async copy."""
+    CAPTURE_SLOTS = 8
 
     def __init__(self, n, device):
         # two pinned staging buffers used in turn: the asynchronous H2D copy of step k may still be pending when the host prepares
@@ -19,20 +20,37 @@ class _PtrTable:
         self.done = [None, None]
         self.turn = 0
         self.last = None
+        # pinned sources of CAPTURED uploads, one slot per capture, allocated here (a pinned allocation inside a capture can itself
+        # invalidate it) and never rewritten once a capture has taken it
+        self.cap_slots = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(self.CAPTURE_SLOTS)]
+        self.cap_used = 0
         self.dev = torch.empty(n, dtype=torch.int64, device=device)
 
     def set(self, values):
-        if self.last == values:                      # unchanged (gradient arena, graph replay): nothing to upload
-            return self.dev
+        capturing = self.dev.is_cuda and torch.cuda.is_current_stream_capturing()
         n = len(values)
+        if capturing:
+            # A captured H2D copy is re-executed by every replay and reads its pinned source THEN: the source must belong to this capture
+            # alone (never one of the two eager staging buffers, which later eager calls overwrite), and the upload is always recorded,
+            # even when the device table already holds these values -- another graph or an eager step may rewrite it between replays.
+            if self.cap_used >= len(self.cap_slots):
+                raise RuntimeError(f"FusedAdamW: more than {len(self.cap_slots)} captures of the optimizer step (raise _PtrTable.CAPTURE_SLOTS)")
+            buf = self.cap_slots[self.cap_used]
+            self.cap_used += 1
+            buf[:n].copy_(torch.tensor(values, dtype=torch.int64))
+            self.dev[:n].copy_(buf[:n], non_blocking=True)
+            self.last = None                         # a replay rewrites self.dev behind the host's back: the next eager call uploads again
+            return self.dev
+        if self.last == values:                      # unchanged (gradient arena, same parameter list): nothing to upload
+            return self.dev
         k = self.turn
         self.turn ^= 1
-        if self.done[k] is not None and not (self.dev.is_cuda and torch.cuda.is_current_stream_capturing()):
-            self.done[k].synchronize()               # (never under capture: an event wait on the host would invalidate it)
+        if self.done[k] is not None:
+            self.done[k].synchronize()
         self.host[k][:n].copy_(torch.tensor(values, dtype=torch.int64))
         self.dev[:n].copy_(self.host[k][:n], non_blocking=True)
         self.done[k] = None
-        if self.dev.is_cuda and not torch.cuda.is_current_stream_capturing():     # (a captured copy replays from a table that no longer changes)
+        if self.dev.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.done[k] = ev

