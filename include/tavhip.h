@@ -163,6 +163,9 @@ typedef struct tav_attn_args {
     int64_t ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     int32_t dtype, mask_mode;
     float scale;
+    int32_t q_prescaled;    /* 1: q already holds q * scale * log2(e) (the caller folded the factor into the q rows of its QKV weight copy, so no
+                               value is rounded twice): the kernels skip one multiply per score and start the running maximum inside the
+                               MFMA accumulator.  Outputs are unchanged: dq / dk / dv are gradients w.r.t. the UNSCALED q, k, v. */
 } tav_attn_args;
 int tav_attn_fwd(const tav_attn_args* args, void* stream);
 int tav_attn_bwd(const tav_attn_args* args, void* stream);
@@ -202,7 +205,8 @@ int tav_ln_bwd_partials(int64_t rows);
 int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int32_t dst_dtype,
                     void* stream);
 /* Multi-tensor form of tav_cast_weight: `descs` is a DEVICE array of n descriptors
- *   { const float* src; void* dst; void* dst_t; int64 ld_dst, ld_dst_t; int32 R, C, dst_dtype, pad }   (48 bytes each)
+ *   { const float* src; void* dst; void* dst_t; int64 ld_dst, ld_dst_t; int32 R, C, dst_dtype; float scale_n }   (48 bytes each)
+ * (scale_n multiplies what is written to dst, NOT dst_t: the attention pre-scale of the q rows, tav_attn_args.q_prescaled)
  * handled by one launch (grid = blocks_per_tensor x n) -- all operand copies of a transformer layer at once. */
 int tav_cast_weights_multi(const void* descs, int32_t n, int32_t blocks_per_tensor, void* stream);
 /* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst) and its dgrad form [k*ci... see DESIGN.md] */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
 TAV_F32, TAV_BF16, TAV_FP8 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -44,7 +44,7 @@ class AttnArgs(C.Structure):
                 ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("delta", vp),
                 ("B", i64), ("S", i64), ("nheads", i64),
                 ("ld_q", i64), ("ld_k", i64), ("ld_v", i64), ("ld_o", i64), ("ld_do", i64), ("ld_dq", i64), ("ld_dk", i64), ("ld_dv", i64),
-                ("dtype", i32), ("mask_mode", i32), ("scale", f32)]
+                ("dtype", i32), ("mask_mode", i32), ("scale", f32), ("q_prescaled", i32)]
 
 
 class LnArgs(C.Structure):

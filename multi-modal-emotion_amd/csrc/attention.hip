@@ -17,6 +17,7 @@
 //   o_q = softmax(s_q) V + c,  c = sum_key mask[key] v[key]   (rank-1, same for every query of a (batch, head)),
 //   backward: dV[key] += mask[key] * sum_q dO_q  and  delta_q = dO_q . (o_q - c).
 #include "common.h"
+#include <type_traits>
 #include "tavhip_internal.h"
 
 // A/B switches (tools/ab_build.sh): issue all LDS fragment reads of a tile ahead of its first MFMA
@@ -41,8 +42,10 @@ struct AttnP {
     int B, S, nh;
     long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     float scale;
+    int pre;       // q holds q * scale * log2(e) already (the QKV projection's q rows were scaled in the weight copy)
 };
 
+TAV_DEV float vmax3(float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 // v_exp_f32 directly (exp2f() adds denormal-range fix-up code; scores are <= 0 after the max subtraction, flush is fine)
 TAV_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -175,21 +178,31 @@ constexpr bool ATT_ABL_NOBAR = false;
 #ifndef TAV_ATT_FWD_OCC
 #define TAV_ATT_FWD_OCC 3      // waves per SIMD the forward kernel is compiled for (register budget 512 / OCC; 4 spills and halves the speed)
 #endif
-template <typename T, int MODE>
+// Lazy running maximum (PRE kernels): the accumulated O / l are rescaled only when a tile's scores exceed the reference exponent by more
+// than this many binary orders of magnitude; until then p = exp2(s - m_ref) may grow to 2^THR, which f32 accumulators and bf16 operands
+// (8-bit exponent) carry without loss.
+#ifndef TAV_ATT_LAZY_THR
+#define TAV_ATT_LAZY_THR 12.0f
+#endif
+// PRE: q is pre-multiplied by scale * log2(e) (the engine folds the factor into the q rows of the QKV weight copy: no extra rounding), so
+// S^T = K q~^T is already the exp2-domain logit.  The unmasked, full tiles then take a fast path built for the VALU issue port, which is
+// what bounds this kernel at head dim 64 (rocprof r03: the port is 81 % busy, the matrix pipe 39 %):
+//   * the running reference exponent enters as the C operand of the first QK^T MFMA (-m on every row of the query's column), so the
+//     accumulators come out as s - m and p = exp2(acc): no fma per score;
+//   * O / l are rescaled only when the tile maximum passes the reference by TAV_ATT_LAZY_THR (rare after the first tile);
+//   * ring slot, LDS addresses and the DMA source walk are compile-time / scalar: the loop body is instantiated once per slot.
+template <typename T, int MODE, bool PRE>
 __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
     // bf16: both tiles live in the swizzled row image (H::row_off), which is linear per 8 rows -- one DMA instruction fills 8 rows x 8
     // slots, the XOR applied to the SOURCE chunk a lane fetches -- and serves the row reads (K) as well as the transposed reads (V,
-    // frag_tr_rowimg).  An ablation priced the register staging (global -> VGPR -> ds_write, address arithmetic per tile) at 25 % of the
-    // kernel (profiles/r02_experiments.md).  f32 keeps the register path and the padded natural V image.
+    // frag_tr_rowimg).  f32 keeps the register path and the padded natural V image.
     constexpr bool DMA = (ES == 2) && TAV_ATT_DMA;
     constexpr int KROW_B = BKV * H::ROWB, VNAT_B = DMA ? BKV * H::ROWB : BKV * H::PITCH_N;
     constexpr int BUF_B = KROW_B + VNAT_B + 2 * BKV * 4;
-    // TAV_ATT_DMA = 2: three buffers, the DMA runs TWO tiles ahead in the unmasked mode (the mask modes' per-tile mask load shares vmcnt).
-    // Measured no faster than one tile ahead: the staging latency is not what this kernel waits for (profiles/r02_experiments.md).
-    constexpr int NBUF = (DMA && MODE == 0 && TAV_ATT_DMA >= 2) ? 3 : 2;
+    constexpr int NBUF = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + NBUF * BUF_B);   // [4][64] + [64]
 
@@ -209,10 +222,25 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
     // softmax runs in the exp2 domain: t = s*scale*log2(e) + mask*log2(e); p = exp2(t - m).  The row sums l come out of the MFMA
     // pipe (a ones-row operand times P^T) instead of 32 VALU adds + shuffles per tile: the kernel is VALU-issue bound.
     constexpr float LOG2E = 1.4426950408889634f;
-    const float c2 = p.scale * LOG2E;
+    const float c2 = PRE ? 1.0f : p.scale * LOG2E;
     const uint4 ones = (ES == 2) ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)
                                  : make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
-    float m_run[2] = {-1e30f, -1e30f};
+    uint4 ones_v = ones;
+    asm volatile("" : "+v"(ones_v.x), "+v"(ones_v.y), "+v"(ones_v.z), "+v"(ones_v.w));   // held in VGPRs (else re-moved from SGPRs every tile)
+    // lane constants of the LDS fragment reads (bf16 row images): K row read of k-step s, V transposed read of d-tile dt; the tile's key
+    // rows and the ring slot are immediates / one scalar add away (row_off's XOR only looks at row bits 1-2, which 16-row steps leave alone)
+    unsigned koff[NSD], vtoff[4];
+    if constexpr (ES == 2) {
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) { koff[s] = (unsigned)H::row_off(i, 4 * s + g); asm volatile("" : "+v"(koff[s])); }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vtoff[dt] = (unsigned)(H::row_off(4 * g + (i >> 2), 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1));
+            asm volatile("" : "+v"(vtoff[dt]));
+        }
+    }
+    float m_run[2] = {-1e30f, -1e30f};                                          // reference exponent of O / l per query (lane i, both q tiles)
+    f32x4 mneg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // PRE fast path: -m_run on all four rows = the C operand of QK^T
     f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // every register = sum_key P[key][q] (rows of the ones operand)
     f32x4 oacc[4][2];
 #pragma unroll
@@ -225,30 +253,43 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
     // gload only ISSUES loads (no arithmetic on a loaded value: that would put a vmcnt wait -- a drain of the whole prefetch --
     // right behind the issue); lstore, one tile of compute later, turns the raw mask value into the per-key additive terms.
     unsigned k_off0[NCH], k_max[NCH], v_off0[NCH], v_max[NCH];
-    tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
-    tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    if constexpr (!DMA) {
+        tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
+        tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    }
     const unsigned kstep_b = (unsigned)(BKV * p.ld_k * ES), vstep_b = (unsigned)(BKV * p.ld_v * ES);
-    // DMA geometry: wave w fills rows [16w, 16w + 16) of both images, 8 rows per instruction; lane -> (row, slot), source chunk = slot ^ swizzle
-    unsigned dk_off[2], dk_max[2], dv_off[2], dv_max[2];
+    // DMA geometry: wave w fills rows [16w, 16w + 16) of both images, 8 rows per instruction; lane -> (row, slot), source chunk = slot ^ swizzle.
+    // The lane offsets are constants of the kernel; the tile walks on the SCALAR base (one s_add per operand), so a regular tile costs no
+    // vector instruction for its addresses.  Only the ragged last tile clamps rows past S (to row S-1: finite data, their scores are -inf).
+    unsigned dk_off[2], dv_off[2];
     unsigned lds_k = 0, lds_v = 0;
     if constexpr (DMA) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
             const int ch = slot ^ (((row >> 1) & 3) << 1);
-            dk_off[j] = (unsigned)(row * p.ld_k * ES + ch * 16); dk_max[j] = (unsigned)((S - 1) * p.ld_k * ES + ch * 16);
-            dv_off[j] = (unsigned)(row * p.ld_v * ES + ch * 16); dv_max[j] = (unsigned)((S - 1) * p.ld_v * ES + ch * 16);
+            dk_off[j] = (unsigned)row * (unsigned)(p.ld_k * ES) + (unsigned)(ch * 16);      // (32-bit: the host checks the slice fits)
+            dv_off[j] = (unsigned)row * (unsigned)(p.ld_v * ES) + (unsigned)(ch * 16);
         }
         lds_k = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 16 * H::ROWB);
         lds_v = lds_k + KROW_B;
     }
-    auto dma = [&](int t, int buf) {                       // rows past S are clamped to row S-1 (finite data; their scores are -inf)
+    // DMA of tile t into slot buf.  RAGGED (the last tile when S is not a multiple of 64): rows past S-1 step back to row S-1 (finite data;
+    // their scores get -inf).  Two instantiations, so the regular tiles carry neither the clamp nor its lane arithmetic.
+    auto dma = [&](int t, int buf, auto ragged_tag) __attribute__((always_inline)) {
+        const char* kb = Kb + (size_t)t * kstep_b;
+        const char* vb = Vb + (size_t)t * vstep_b;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            unsigned ok = dk_off[j] + t * kstep_b; ok = ok < dk_max[j] ? ok : dk_max[j];
-            unsigned ov = dv_off[j] + t * vstep_b; ov = ov < dv_max[j] ? ov : dv_max[j];
-            glds16_s(Kb, ok, lds_k + buf * BUF_B + j * 1024);
-            glds16_s(Vb, ov, lds_v + buf * BUF_B + j * 1024);
+            unsigned ok = dk_off[j], ov = dv_off[j];
+            if constexpr (decltype(ragged_tag)::value) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                 // (re-materialised here: nothing of this is hoisted above the loop and kept live)
+                const int over = t * BKV + wave * 16 + j * 8 + (ln >> 3) - (S - 1);
+                if (over > 0) { ok -= (unsigned)over * (unsigned)(p.ld_k * ES); ov -= (unsigned)over * (unsigned)(p.ld_v * ES); }
+            }
+            glds16_s(kb, ok, lds_k + buf * BUF_B + j * 1024);
+            glds16_s(vb, ov, lds_v + buf * BUF_B + j * 1024);
         }
     };
     auto gload = [&](int t) {
@@ -262,136 +303,165 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
             r_mask = maskb[key];
         }
     };
+    // per-key additive terms of tile t -> slot buf.  Without a mask only the ragged last tile reads them.
     auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
         if constexpr (!DMA) {
             tile_lstore_row<T, BKV>(rk, base, tid);
             tile_lstore_nat<T, BKV>(rv, base + KROW_B, tid);
         }
-        if (tid < BKV) {
+        if ((MODE != 0 || t == nkt - 1) && tid < BKV) {
             const bool ok = t * BKV + tid < S;
             float* f = reinterpret_cast<float*>(base + KROW_B + VNAT_B);
             f[tid] = ok ? (MODE == 1 ? r_mask * 1.4426950408889634f : 0.f) : -INFINITY;   // already in the exp2 domain
             f[BKV + tid] = (MODE == 2 && ok) ? r_mask : 0.f;
         }
     };
-    if constexpr (DMA) { dma(0, 0); if (NBUF == 3 && nkt > 1) dma(1, 1); }
+    using TagNo = std::integral_constant<int, 0>;
+    using TagYes = std::integral_constant<int, 1>;
+    if constexpr (DMA) { if (nkt == 1) dma(0, 0, TagYes{}); else dma(0, 0, TagNo{}); }
     gload(0); lstore(0, 0);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int s = 0; s < NSD; ++s) settle(qf[qt][s]);
-    if constexpr (DMA) {
-        if (NBUF == 3 && nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile 0 landed, tile 1 (4 younger instructions) may fly
-        else wait_vmcnt0();
-    }
+    if constexpr (DMA) wait_vmcnt0();
     __syncthreads();
 
-    for (int t = 0; t < nkt; ++t) {
-        const int cur = NBUF == 3 ? t % 3 : (t & 1);
-        const int nxt = NBUF == 3 ? (t + 1) % 3 : (cur ^ 1);
-        if constexpr (DMA) {                                // (the refilled buffer was last read in iteration t-1, behind a barrier)
-            if (NBUF == 3) { if (t + 2 < nkt && !ATT_ABL_NOGLOAD) dma(t + 2, (t + 2) % 3); }
-            else if (t + 1 < nkt && !ATT_ABL_NOGLOAD) dma(t + 1, nxt);
+    // One K/V tile.  KADD (compile time): the tile adds per-key terms (pre-softmax mask, -inf past S): every tile under MODE 1, else only the
+    // last one, which is peeled off the loop -- the loop body itself has a single softmax path.  NEXT: 0 no prefetch, 1 regular, 2 ragged tile.
+    auto tile_body = [&](const int t, auto kadd_tag, auto next_tag) __attribute__((always_inline)) {
+        constexpr bool KADD = decltype(kadd_tag)::value != 0;
+        constexpr int NEXT = decltype(next_tag)::value;
+        const int cur = t & 1, nxt = cur ^ 1;
+        if constexpr (NEXT != 0 && !ATT_ABL_NOGLOAD) {           // (slot nxt was last read in iteration t-1, behind a barrier)
+            if constexpr (DMA) dma(t + 1, nxt, std::integral_constant<int, NEXT == 2>{});
+            gload(t + 1);
         }
-        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) gload(t + 1);
         const char* Krow = smem + cur * BUF_B;
         const char* Vnat = Krow + KROW_B;
         const float* kadd = reinterpret_cast<const float*>(Vnat + VNAT_B);
         const float* cm = kadd + BKV;
 
         f32x4 sacc[4][2];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { sacc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sacc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // bf16: every LDS read of the tile (8 K-row + 16 transposed V fragments, 64 VGPRs) is issued up front, so the V
-        // fragments arrive under the QK^T MFMAs and the softmax instead of costing an exposed LDS round trip per PV group.
-        constexpr int NKS = BKV / KSTEP;
-        constexpr bool HOIST = (ES == 2) && TAV_HOIST_FWD;
-        uint4 kfr[HOIST ? 4 : 1][HOIST ? NSD : 1], vfr[HOIST ? NKS : 1][HOIST ? 4 : 1];
-        if constexpr (HOIST) {
-#pragma unroll
-            for (int s = 0; s < NSD; ++s)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) kfr[kt][s] = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    if constexpr (DMA) vfr[ks][dt] = frag_tr_rowimg(Vnat, ks * KSTEP, dt, lane);
-                    else vfr[ks][dt] = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+        // S^T = K q^T: the accumulators start at cinit (fast path: -m_ref on every row, so s - m_ref comes out of the MFMA chain; else zero)
+        auto qk = [&](const f32x4 (&cinit)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NSD; ++s)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    ATT_FWD_MMA(kfr[kt][s], qf[0][s], sacc[kt][0]);
-                    ATT_FWD_MMA(kfr[kt][s], qf[1][s], sacc[kt][1]);
+                    uint4 a;
+                    if constexpr (ES == 2) a = *reinterpret_cast<const uint4*>(Krow + koff[s] + kt * 16 * H::ROWB);
+                    else a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        if (s == 0) sacc[kt][qt] = cinit[qt];
+                        ATT_FWD_MMA(a, qf[qt][s], sacc[kt][qt]);
+                    }
                 }
-        } else {
+        };
+        if constexpr (PRE && !KADD) {
+            qk(mneg);
+            // sacc = s - m_ref.  Tile maximum per query; rescale only when it passes the reference by more than THR (or on the first tile,
+            // where the reference is still undefined: mneg = 0, so sacc are the raw logits).
+            const bool first = (t == 0);
+            float mx[2];
+            bool grow = first;
 #pragma unroll
-            for (int s = 0; s < NSD; ++s)
+            for (int qt = 0; qt < 2; ++qt) {
+                // v_maximum3_f32 (IEEE maximum: no canonicalising v_max in front of MFMA results, as fmaxf needs): 8 instructions for 16 values
+                float m0 = vmax3(sacc[0][qt][0], sacc[0][qt][1], sacc[0][qt][2]);
+                m0 = vmax3(m0, sacc[0][qt][3], sacc[1][qt][0]);
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
-                    ATT_FWD_MMA(a, qf[0][s], sacc[kt][0]);
-                    ATT_FWD_MMA(a, qf[1][s], sacc[kt][1]);
+                for (int kt = 1; kt < 4; ++kt) {
+                    if (kt > 1) m0 = vmax3(m0, sacc[kt - 1][qt][3], sacc[kt][qt][0]);
+                    m0 = vmax3(m0, sacc[kt][qt][1], sacc[kt][qt][2]);
                 }
-        }
-        // running max per query (= per lane i, both q tiles), then p = exp2(s*c2 + kadd - m).  The per-key additive term is zero
-        // except under a pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S): only those tiles pay for it;
-        // the others take the max over the raw scores and fold scale and max into one fma per element.
-        float alpha[2];
-        bool moved = false;
-        const bool with_kadd = (MODE == 1) || (t == nkt - 1);
-        if (with_kadd) {
-            float mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
+                m0 = __builtin_elementwise_maximum(m0, sacc[3][qt][3]);
+                mx[qt] = max_over_row_groups(m0);
+                grow |= mx[qt] > TAV_ATT_LAZY_THR;
+            }
+            if (__any(grow)) {                                     // rare after the first tile: move the reference, THEN take the common path
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    sacc[kt][qt] = sacc[kt][qt] * c2 + ka;
-                    mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                    const float shift = first ? mx[qt] : fmaxf(mx[qt], 0.f);         // new reference = old + shift (never lowered after tile 0)
+                    m_run[qt] = first ? shift : m_run[qt] + shift;
+                    mneg[qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) sacc[kt][qt] -= shift;
+                    if (!first) {                                   // (O = l = 0 on the first tile; exp2(-shift) could overflow there)
+                        const float al = ATT_FWD_EXP2(-shift);
+                        lacc[qt] *= al;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= al;
+                    }
                 }
             }
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx[qt]));
-                alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
-                moved |= m_new > m_run[qt];
-                m_run[qt] = m_new;
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(sacc[kt][qt][r] - m_new);
-            }
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(sacc[kt][qt][r]);
         } else {
+            const f32x4 zero2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            qk(zero2);
+            // running max per query (= per lane i, both q tiles), then p = exp2(s*c2 + kadd - m).  The per-key additive term is zero
+            // except under a pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S): only those tiles pay for it;
+            // the others take the max over the raw scores and fold scale and max into one fma per element.
+            float alpha[2];
+            bool moved = false;
+            if constexpr (KADD) {
+                float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
 #pragma unroll
-                for (int kt = 1; kt < 4; ++kt)
-                    mx = fmaxf(fmaxf(mx, sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
-                const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx) * c2);
-                alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
-                moved |= m_new > m_run[qt];
-                m_run[qt] = m_new;
+                    for (int qt = 0; qt < 2; ++qt) {
+                        sacc[kt][qt] = PRE ? sacc[kt][qt] + ka : sacc[kt][qt] * c2 + ka;
+                        mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                    }
+                }
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int qt = 0; qt < 2; ++qt) {
+                    const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx[qt]));
+                    alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
+                    moved |= m_new > m_run[qt];
+                    m_run[qt] = m_new;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(__builtin_fmaf(sacc[kt][qt][r], c2, -m_new));
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(sacc[kt][qt][r] - m_new);
+                }
+            } else {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+                    for (int kt = 1; kt < 4; ++kt)
+                        mx = fmaxf(fmaxf(mx, sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+                    const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx) * c2);
+                    alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
+                    moved |= m_new > m_run[qt];
+                    m_run[qt] = m_new;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(__builtin_fmaf(sacc[kt][qt][r], c2, -m_new));
+                }
             }
-        }
-        if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
+            if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                lacc[qt] *= alpha[qt];
+                for (int qt = 0; qt < 2; ++qt) {
+                    lacc[qt] *= alpha[qt];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha[qt];
+                    for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha[qt];
+                    if constexpr (PRE && MODE != 1) mneg[qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
+                }
             }
         }
         // O^T += V^T P^T ;  l += 1^T P^T
+        constexpr int NKS = BKV / KSTEP;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             uint4 pb[2];
@@ -402,13 +472,16 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                 tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
                 pb[qt] = acc_to_kfrag<T>(tl);
             }
-            ATT_FWD_MMA(ones, pb[0], lacc[0]);
-            ATT_FWD_MMA(ones, pb[1], lacc[1]);
+            ATT_FWD_MMA(ones_v, pb[0], lacc[0]);
+            ATT_FWD_MMA(ones_v, pb[1], lacc[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint4 a;
-                if constexpr (HOIST) a = vfr[ks][dt];
-                else if constexpr (DMA) a = frag_tr_rowimg(Vnat, ks * KSTEP, dt, lane);
+                if constexpr (DMA) {                          // = frag_tr_rowimg(Vnat, ks * KSTEP, dt, lane) with the lane part precomputed
+                    const char* vt = Vnat + vtoff[dt] + ks * KSTEP * H::ROWB;
+                    const uint2 lo = lds_read_tr16(vt), hi = lds_read_tr16(vt + 16 * H::ROWB);
+                    a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
                 else a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
                 ATT_FWD_MMA(a, pb[0], oacc[dt][0]);
                 ATT_FWD_MMA(a, pb[1], oacc[dt][1]);
@@ -423,13 +496,15 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                 else corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
             }
         }
-        if (t + 1 < nkt && !ATT_ABL_NOGLOAD) lstore(t + 1, nxt);
-        if constexpr (DMA) {                                // tile t+1 must have landed; tile t+2's four instructions may still fly
-            if (NBUF == 3 && t + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else wait_vmcnt0();
-        }
+        if constexpr (NEXT != 0 && !ATT_ABL_NOGLOAD) lstore(t + 1, nxt);
+        if constexpr (DMA) wait_vmcnt0();                     // tile t+1 has landed
         if (!ATT_ABL_NOBAR) __syncthreads();
-    }
+    };
+    using K0 = std::integral_constant<int, (MODE == 1) ? 1 : 0>;      // middle tiles carry per-key terms only under the pre-softmax mask
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile_body(t, K0{}, std::integral_constant<int, 1>{});
+    if (t + 1 < nkt) { tile_body(t, K0{}, std::integral_constant<int, 2>{}); ++t; }
+    tile_body(t, TagYes{}, std::integral_constant<int, 0>{});          // the last tile: -inf past S
 
     if (MODE == 2) {
         red[wave * 64 + lane] = corr_part;
@@ -499,7 +574,7 @@ template <typename T> constexpr int dkdv_bq() { return sizeof(T) == 2 ? TAV_DKDV
 #ifndef TAV_ATT_DQ_OCC
 #define TAV_ATT_DQ_OCC 2
 #endif
-template <typename T, int MODE>
+template <typename T, int MODE, bool PRE>
 __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T>(), NQT = BQ / 16;
@@ -532,7 +607,10 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
         kadd[kt] = ok ? (MODE == 1 ? mv * 1.4426950408889634f : 0.f) : -INFINITY;    // exp2 domain
         cmk[kt] = (MODE == 2) ? mv : 0.f;
     }
-    const float c2 = p.scale * 1.4426950408889634f, inv_scale = 1.0f / p.scale;
+    // PRE: q holds q * scale * log2(e), so S = q~ k^T is the exp2-domain logit: the accumulators start at -lse * log2(e) and p = exp2(acc)
+    // without a multiply; dK = sum dS q comes out in units of q~ and is brought back with ln 2 instead of the softmax scale.
+    const float c2 = PRE ? 1.0f : p.scale * 1.4426950408889634f, lse_mul = PRE ? 1.4426950408889634f : 1.0f / p.scale;
+    const float dk_mul = PRE ? 0.6931471805599453f : p.scale;
     f32x4 dVt[4][2], dKt[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -571,7 +649,7 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
         if (tid < BQ) {
             const bool ok = t * BQ + tid < S;
             float* f = reinterpret_cast<float*>(base + 2 * ROW_B + 2 * NAT_B);
-            f[tid] = ok ? -r_lse * inv_scale : -INFINITY;   // S accumulators start at -lse/scale; -inf => p = 0 for rows past S
+            f[tid] = ok ? -r_lse * lse_mul : -INFINITY;     // S accumulators start at -lse/scale (PRE: -lse*log2e); -inf => p = 0 for rows past S
             f[BQ + tid] = ok ? -r_delta : 0.f;                // dP accumulators start at -delta
         }
     };
@@ -625,12 +703,12 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(__builtin_fmaf(sacc[qt][kt][r], c2, kadd[kt]));
+                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(PRE ? sacc[qt][kt][r] + kadd[kt] : __builtin_fmaf(sacc[qt][kt][r], c2, kadd[kt]));
             } else {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(sacc[qt][kt][r] * c2);
+                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(PRE ? sacc[qt][kt][r] : sacc[qt][kt][r] * c2);
             }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -685,14 +763,14 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
                 f32x4 dvv = dVt[dt][kt];
                 if (MODE == 2) dvv += *reinterpret_cast<const f32x4*>(red + 256 + 16 * dt + 4 * g) * cmk[kt];
                 st4(dvrow + 16 * dt + 4 * g, dvv);
-                st4(dkrow + 16 * dt + 4 * g, dKt[dt][kt] * p.scale);
+                st4(dkrow + 16 * dt + 4 * g, dKt[dt][kt] * dk_mul);
             }
         }
     }
 }
 
 // ================================================================================================= backward: dQ
-template <typename T, int MODE>
+template <typename T, int MODE, bool PRE>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void attn_bwd_dq_kernel(const AttnP p) {
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
@@ -719,10 +797,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
         row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q, S, g);
         row_frags_gload<T>(dof[qt], dOb, p.ld_do * ES, q, S, g);
         if (q >= S) q = S - 1;
-        lse_q[qt] = -p.lse[((long)b * p.nh + head) * S + q] / p.scale;      // S accumulators start at -lse/scale, dP at -delta
+        lse_q[qt] = -p.lse[((long)b * p.nh + head) * S + q] * (PRE ? 1.4426950408889634f : 1.0f / p.scale);   // S accumulators start at -lse/scale (PRE: -lse*log2e), dP at -delta
         delta_q[qt] = -p.delta[((long)b * p.nh + head) * S + q];           // (row constants as the initial accumulators)
     }
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = PRE ? 1.0f : p.scale * 1.4426950408889634f;
     f32x4 dQt[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { dQt[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dQt[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -797,7 +875,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(__builtin_fmaf(sacc[kt][qt][r], c2, ka[r])) * dpacc[kt][qt][r];
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(PRE ? sacc[kt][qt][r] + ka[r] : __builtin_fmaf(sacc[kt][qt][r], c2, ka[r])) * dpacc[kt][qt][r];
             }
         } else {
 #pragma unroll
@@ -805,7 +883,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(sacc[kt][qt][r] * c2) * dpacc[kt][qt][r];
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = fast_exp2(PRE ? sacc[kt][qt][r] : sacc[kt][qt][r] * c2) * dpacc[kt][qt][r];
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -837,8 +915,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
     }
 }
 
-template <typename T> constexpr size_t fwd_lds() {           // (bf16: room for the three-buffer DMA ring of the unmasked forward)
-    return ((HD<T>::ES == 2 && TAV_ATT_DMA >= 2) ? 3 : 2) * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
+template <typename T> constexpr size_t fwd_lds() {
+    return 2 * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
 }
 template <typename T> constexpr size_t dkdv_lds() {
     return 2 * (2 * dkdv_bq<T>() * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * dkdv_bq<T>() * HD<T>::PITCH_N) + 2 * dkdv_bq<T>() * 4) + (256 + 64) * 4;
@@ -877,21 +955,28 @@ static AttnP pack(const tav_attn_args* a) {
     p.ld_q = a->ld_q; p.ld_k = a->ld_k; p.ld_v = a->ld_v; p.ld_o = a->ld_o; p.ld_do = a->ld_do;
     p.ld_dq = a->ld_dq; p.ld_dk = a->ld_dk; p.ld_dv = a->ld_dv;
     p.scale = a->scale;
+    p.pre = a->q_prescaled != 0;
     return p;
 }
 
-template <typename T, int MODE> static int launch_fwd(const AttnP& p, hipStream_t st) {
+template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, hipStream_t st) {
     dim3 grid((p.S + 127) / 128, p.nh, p.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, MODE>), grid, dim3(256), fwd_lds<T>(), st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, PRE>), grid, dim3(256), fwd_lds<T>(), st, p);
     return (int)hipGetLastError();
 }
-template <typename T, int MODE> static int launch_bwd(const AttnP& p, hipStream_t st) {
+template <typename T, int MODE, bool PRE> static int launch_bwd(const AttnP& p, hipStream_t st) {
     const long rows = (long)p.B * p.S * p.nh;
     hipLaunchKernelGGL((attn_bwd_delta_kernel<T, MODE>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, p);
     dim3 grid((p.S + 127) / 128, p.nh, p.B);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE>), grid, dim3(256), dkdv_lds<T>(), st, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE>), grid, dim3(256), dq_lds<T>(), st, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), dkdv_lds<T>(), st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, p);
     return (int)hipGetLastError();
+}
+template <typename T, bool PRE> static int dispatch_fwd(const AttnP& p, int mode, hipStream_t st) {
+    switch (mode) { case 0: return launch_fwd<T, 0, PRE>(p, st); case 1: return launch_fwd<T, 1, PRE>(p, st); default: return launch_fwd<T, 2, PRE>(p, st); }
+}
+template <typename T, bool PRE> static int dispatch_bwd(const AttnP& p, int mode, hipStream_t st) {
+    switch (mode) { case 0: return launch_bwd<T, 0, PRE>(p, st); case 1: return launch_bwd<T, 1, PRE>(p, st); default: return launch_bwd<T, 2, PRE>(p, st); }
 }
 
 }  // namespace tav
@@ -903,10 +988,8 @@ extern "C" int tav_attn_fwd(const tav_attn_args* a, void* stream) {
     if (e) return e;
     const AttnP p = pack(a);
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == TAV_BF16) {
-        switch (a->mask_mode) { case 0: return launch_fwd<bf16, 0>(p, st); case 1: return launch_fwd<bf16, 1>(p, st); default: return launch_fwd<bf16, 2>(p, st); }
-    }
-    switch (a->mask_mode) { case 0: return launch_fwd<float, 0>(p, st); case 1: return launch_fwd<float, 1>(p, st); default: return launch_fwd<float, 2>(p, st); }
+    if (a->dtype == TAV_BF16) return p.pre ? dispatch_fwd<bf16, true>(p, a->mask_mode, st) : dispatch_fwd<bf16, false>(p, a->mask_mode, st);
+    return p.pre ? dispatch_fwd<float, true>(p, a->mask_mode, st) : dispatch_fwd<float, false>(p, a->mask_mode, st);
 }
 
 extern "C" int tav_attn_bwd(const tav_attn_args* a, void* stream) {
@@ -914,8 +997,6 @@ extern "C" int tav_attn_bwd(const tav_attn_args* a, void* stream) {
     if (e) return e;
     const AttnP p = pack(a);
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == TAV_BF16) {
-        switch (a->mask_mode) { case 0: return launch_bwd<bf16, 0>(p, st); case 1: return launch_bwd<bf16, 1>(p, st); default: return launch_bwd<bf16, 2>(p, st); }
-    }
-    switch (a->mask_mode) { case 0: return launch_bwd<float, 0>(p, st); case 1: return launch_bwd<float, 1>(p, st); default: return launch_bwd<float, 2>(p, st); }
+    if (a->dtype == TAV_BF16) return p.pre ? dispatch_bwd<bf16, true>(p, a->mask_mode, st) : dispatch_bwd<bf16, false>(p, a->mask_mode, st);
+    return p.pre ? dispatch_bwd<float, true>(p, a->mask_mode, st) : dispatch_bwd<float, false>(p, a->mask_mode, st);
 }

@@ -28,7 +28,7 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, TD* __restrict
 }
 
 // Multi-tensor form: blockIdx.y selects a descriptor (one launch refreshes every operand copy of a transformer layer).
-struct CastDesc { const float* src; void* dst; void* dst_t; long ld_n, ld_t; int R, C, dtype, pad; };
+struct CastDesc { const float* src; void* dst; void* dst_t; long ld_n, ld_t; int R, C, dtype; float scale_n; };   // scale_n: factor on the values written to dst (not dst_t)
 // bf16 matrices with R, C multiples of 64 and both copies wanted (every GEMM weight): 64x64 tiles, 16-B loads, 8-B stores (128-B row
 // segments) -- the 32x32 / 2-B-store form below ran at 2.1 TB/s
 __device__ void cast_weight_tile64(const CastDesc& d, float (*tile)[65], int t, int tiles_c) {
@@ -38,7 +38,7 @@ __device__ void cast_weight_tile64(const CastDesc& d, float (*tile)[65], int t, 
     for (int i = 0; i < 4; ++i) {
         const int row = h + 16 * i;
         const f32x4 v = ld4(d.src + (long)(r0 + row) * d.C + c0 + 4 * q);
-        st4((bf16*)d.dst + (long)(r0 + row) * d.ld_n + c0 + 4 * q, v);
+        st4((bf16*)d.dst + (long)(r0 + row) * d.ld_n + c0 + 4 * q, v * d.scale_n);
         tile[row][4 * q] = v[0]; tile[row][4 * q + 1] = v[1]; tile[row][4 * q + 2] = v[2]; tile[row][4 * q + 3] = v[3];
     }
     __syncthreads();
@@ -67,7 +67,7 @@ __global__ void cast_weight_multi_kernel(const CastDesc* __restrict__ descs) {
             float v = 0.f;
             if (r < d.R && c < d.C) {
                 v = d.src[(long)r * d.C + c];
-                if (d.dst) { if (d.dtype == TAV_BF16) ET<bf16>::st((bf16*)d.dst + (long)r * d.ld_n + c, v); else ((float*)d.dst)[(long)r * d.ld_n + c] = v; }
+                if (d.dst) { if (d.dtype == TAV_BF16) ET<bf16>::st((bf16*)d.dst + (long)r * d.ld_n + c, v * d.scale_n); else ((float*)d.dst)[(long)r * d.ld_n + c] = v * d.scale_n; }
             }
             tile[k][tx] = v;
         }

@@ -44,6 +44,16 @@ class Policy:
         # "fp8-wgrad8"/"fp8-all": e4m3 NT GEMMs of transposed quantised copies split over the token axis.  At config 5 / batch 16 the bf16 form wins
         # since the 256-wide weight-gradient tile exists (profiles/r02_experiments.md).
         self.fp8_wgrad8 = name in ("fp8-wgrad8", "fp8-all")
+        # which of a layer's GEMMs take e4m3 operands: bit 0 qkv, 1 out-proj, 2 FFN1, 3 FFN2 -- forward (fwd) and their dgrads (bwd).
+        # The others run the bf16 kernels.  (TAV_FP8_FWD_MASK / TAV_FP8_BWD_MASK: error-attribution experiments, tools/gpu_fp8_attrib.py.)
+        # Default (round 3, measured at config 5's REAL depth, 24 video layers, profiles/r03_fp8_attribution.txt): only the QKV projection keeps
+        # e4m3 in the forward pass -- its rounding is averaged by the softmax (logits 6.1e-3 vs bf16's 5.4e-3) -- while e4m3 out-proj /
+        # FFN1 / FFN2 inputs each cost 1.5e-2 .. 2.2e-2 on the logits, over the 1e-2 budget on their own; all four dgrads stay on e4m3
+        # (grad-norm 6.5e-4).  "fp8-all" / "fp8-wgrad8" remain the all-e4m3 throughput experiments.
+        self.fp8_fwd = int(os.environ.get("TAV_FP8_FWD_MASK", "15" if name == "fp8-all" else "1")) if self.fp8 else 0
+        self.fp8_bwd = int(os.environ.get("TAV_FP8_BWD_MASK", "15")) if self.fp8 else 0
+        if self.fp8_wgrad8:
+            self.fp8_fwd = self.fp8_bwd = 15             # (the e4m3 weight gradients read the transposed quantised copies of every operand)
 
 
 class WeightCache:
@@ -97,11 +107,14 @@ class WeightCache:
             return n, t, bias
         return self._get(("qkv", id(wq)), (wq, wk, wv, bq, bk, bv), build)
 
-    def layer(self, wq, wk, wv, bq, bk, bv, wo, w1, w2):
+    def layer(self, wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=None):
         """All GEMM operands of one transformer layer, refreshed by ONE multi-tensor launch when any of them changed:
         -> (Wqkv [3H,K], Wqkv^T [K,3H], bias_qkv [3H] f32, Wo, Wo^T, W1, W1^T, W2, W2^T).  Buffers and the device descriptor
-        table are created once (parameter storage is stable), so the refresh is graph-capturable and allocation free."""
-        key = ("layer", id(wq))
+        table are created once (parameter storage is stable), so the refresh is graph-capturable and allocation free.
+        q_scale: factor folded into the q rows of the FORWARD operand Wqkv and of bias_qkv (ops.ATTN_Q_PRESCALE: the attention kernels
+        then get q * scale * log2(e) straight from the projection, rounded once).  Wqkv^T -- the dgrad operand -- stays unscaled: the
+        attention backward returns the gradient w.r.t. the unscaled q."""
+        key = ("layer", id(wq), q_scale)
         params = (wq, wk, wv, bq, bk, bv, wo, w1, w2)
         ver = (_EPOCH[0],) + tuple(p._version for p in params if p is not None)
         e = self.d.get(key)
@@ -118,9 +131,10 @@ class WeightCache:
                 bias = ops.zeros_f32((3 * H,), dev)
                 ents = []
                 for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-                    ents.append((w.detach(), n[j * H:(j + 1) * H], t[:, j * H:(j + 1) * H]))
+                    sc = q_scale if j == 0 else None
+                    ents.append((w.detach(), n[j * H:(j + 1) * H], t[:, j * H:(j + 1) * H], sc))
                     if b is not None:
-                        ents.append((b.detach().view(1, H), bias[j * H:(j + 1) * H].view(1, H), None))
+                        ents.append((b.detach().view(1, H), bias[j * H:(j + 1) * H].view(1, H), None, sc))
                 outs = [n, t, bias]
                 for w in (wo, w1, w2):
                     wn_ = torch.empty(w.shape, dtype=lp, device=dev)
@@ -212,6 +226,8 @@ class LayerSpec:
 
 
 GROUPED_WGRAD = [os.environ.get("TAV_GROUPED_WGRAD", "1") == "1"]
+# attention pre-scale of the q rows (see WeightCache.layer); TAV_ATTN_PRESCALE=0 keeps q unscaled (the round-2 kernels' convention, A/B)
+QSC = ops.ATTN_Q_PRESCALE if os.environ.get("TAV_ATTN_PRESCALE", "1") == "1" else None
 
 
 def _layer_wgrads(pairs):
@@ -239,7 +255,8 @@ class EncoderLayerFn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        # the q third of qkv comes out of the projection already multiplied by scale * log2(e) (folded into the weight copy)
+        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
         x = _c(x)
         if spec.pre_ln:
             _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
@@ -247,7 +264,7 @@ class EncoderLayerFn(torch.autograd.Function):
             a = x_lp if x_lp is not None else _to_lp(pol, x)
             mean1 = rstd1 = None
         qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
-        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
         y1 = ops.gemm_nt(o, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
         if spec.pre_ln:
             x1 = y1
@@ -281,7 +298,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[17:]
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
         g2 = _c(g2)
         if spec.pre_ln:
             hint = None if pol.f32 else _hint_take(g2)
@@ -301,7 +318,7 @@ class EncoderLayerFn(torch.autograd.Function):
         # attention
         do = ops.gemm_nt(dy1_lp, wo_t)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
-                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
         if spec.pre_ln:
             da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON and not pol.f32)
@@ -329,28 +346,42 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        bqkv = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)[2]
+        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
         wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        fm = pol.fp8_fwd
+        a8 = o8 = c8 = h8 = None
         x = _c(x)
         if spec.pre_ln:
             _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
         else:
             a = x_lp if x_lp is not None else _to_lp(pol, x)
             mean1 = rstd1 = None
-        a8 = ops.fp8_quantize(a, want_t=pol.fp8_wgrad8)
-        qkv = ops.gemm_nt_fp8(a8, wqkv8, bias=bqkv)
+        if fm & 1:
+            a8 = ops.fp8_quantize(a, want_t=pol.fp8_wgrad8)
+            qkv = ops.gemm_nt_fp8(a8, wqkv8, bias=bqkv)
+        else:
+            qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
         o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8)
-        y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
+        if fm & 2:
+            o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8)
+            y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
+        else:
+            y1 = ops.gemm_nt(o, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
         if spec.pre_ln:
             x1 = y1
             _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
         else:
             x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
-        c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8)
-        h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
-        h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8)
-        y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
+        if fm & 4:
+            c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8)
+            h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
+        else:
+            h, u = ops.gemm_nt(c, w1_n, bias=b1, act=3, want_pre=True)
+        if fm & 8:
+            h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8)
+            y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
+        else:
+            y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=x1, out_dtype=torch.float32)
         if spec.pre_ln:
             x2, x2_lp = y2, None
         else:
@@ -381,12 +412,17 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         B, S, nh = spec.B, spec.S, spec.nheads
         H, F, M = nh * 64, w1.shape[0], ctx.rows
         wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
         w8 = pol.fp8_wgrad8
+        bm = pol.fp8_bwd
         if w8:
             a8, o8, c8, h8 = (ops.Fp8(None, t, s, M, t.shape[0]) for t, s in ((a_t, a_s), (o_t, o_s), (c_t, c_s), (h_t, h_s)))
 
-        def dgrad(dy8, w8, **kw):            # dY [M, N] x W [N, K] -> [M, K]: the NT GEMM against the transposed copy W^T [K, N_pad]
-            return ops.gemm_nt(dy8.q, w8.qt[:, :w8.rows], a_dequant=dy8.dequant, b_dequant=w8.dequant, **kw)
+        def dgrad(dy_lp, bit, wq8, w_t, **kw):   # dY [M, N] x W [N, K] -> [M, K]: the NT GEMM against the transposed copy W^T [K, N(_pad)]
+            if bm & bit:
+                dy8 = ops.fp8_quantize(dy_lp, want_t=w8)
+                return ops.gemm_nt(dy8.q, wq8.qt[:, :wq8.rows], a_dequant=dy8.dequant, b_dequant=wq8.dequant, **kw), dy8
+            return ops.gemm_nt(dy_lp, w_t, **kw), None
 
         g2 = _c(g2)
         if spec.pre_ln:
@@ -395,27 +431,23 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
             dg2 = db2 = None
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
-        dy28 = ops.fp8_quantize(dy2_lp, want_t=w8)
-        du = dgrad(dy28, w28, gelu_in=u, act=4)
-        du8 = ops.fp8_quantize(du, want_t=w8)
+        du, dy28 = dgrad(dy2_lp, 1, w28, w2_t, gelu_in=u, act=4)
         if spec.pre_ln:
-            dc = dgrad(du8, w18, out_dtype=torch.float32)
+            dc, du8 = dgrad(du, 2, w18, w1_t, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
             dy1, dy1_lp = g1, g1_lp
         else:
-            g1 = dgrad(du8, w18, resid=dy2, out_dtype=torch.float32)
+            g1, du8 = dgrad(du, 2, w18, w1_t, resid=dy2, out_dtype=torch.float32)
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
-        dy18 = ops.fp8_quantize(dy1_lp, want_t=w8)
-        do = dgrad(dy18, wo8)
+        do, dy18 = dgrad(dy1_lp, 4, wo8, wo_t)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
-        dqkv8 = ops.fp8_quantize(dqkv, want_t=w8)
         if spec.pre_ln:
-            da = dgrad(dqkv8, wqkv8, out_dtype=torch.float32)
+            da, dqkv8 = dgrad(dqkv, 8, wqkv8, wqkv_t, out_dtype=torch.float32)
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON)
             _hint_set(g0, g0_lp)
         else:
-            g0 = dgrad(dqkv8, wqkv8, resid=dy1, out_dtype=torch.float32)
+            g0, dqkv8 = dgrad(dqkv, 8, wqkv8, wqkv_t, resid=dy1, out_dtype=torch.float32)
         if w8:
             dW2, dW1, dWo, dWqkv = ops.wgrad_fp8(dy28, h8), ops.wgrad_fp8(du8, c8), ops.wgrad_fp8(dy18, o8), ops.wgrad_fp8(dqkv8, a8)
             dB2, dB1, dBo, dBqkv = ops.colsum(dy2_lp), ops.colsum(du), ops.colsum(dy1_lp), ops.colsum(dqkv)

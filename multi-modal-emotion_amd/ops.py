@@ -213,29 +213,33 @@ def colsum(x, *, out=None, accumulate=False, M=None, N=None, ld=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft=None):
+def _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft=None, q_prescaled=False):
     a = L.AttnArgs()
     a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(o)
     a.key_mask, a.lse, a.corr, a.o_soft = ptr(key_mask), ptr(lse), ptr(corr), ptr(o_soft)
     a.B, a.S, a.nheads = B, S, nheads
     a.ld_q, a.ld_k, a.ld_v, a.ld_o = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
-    a.dtype, a.mask_mode, a.scale = dt(q), mask_mode, scale
+    a.dtype, a.mask_mode, a.scale, a.q_prescaled = dt(q), mask_mode, scale, int(bool(q_prescaled))
     return a
 
 
-def attn_fwd(q, k, v, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125):
-    """q,k,v: [B*S, >=nheads*64] views (row stride arbitrary).  Returns o [B*S, nheads*64], lse, corr."""
+ATTN_Q_PRESCALE = 0.125 * 1.4426950408889634      # what a prescaled q carries: softmax scale (head dim 64) x log2(e)
+
+
+def attn_fwd(q, k, v, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, q_prescaled=False):
+    """q,k,v: [B*S, >=nheads*64] views (row stride arbitrary).  Returns o [B*S, nheads*64], lse, corr.
+    q_prescaled: q already holds q * scale * log2(e) (tav_attn_args.q_prescaled)."""
     H = nheads * 64
     o = torch.empty(B * S, H, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, nheads, S, dtype=torch.float32, device=q.device)
     corr = torch.empty(B, nheads, 64, dtype=torch.float32, device=q.device) if mask_mode == 2 else None
     o_soft = torch.empty_like(o) if mask_mode == 2 else None
-    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft)
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft, q_prescaled)
     check(lib().tav_attn_fwd(C.byref(a), stream()), "attn_fwd")
     return o, lse, (corr, o_soft)
 
 
-def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, dqkv=None):
+def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, dqkv=None, q_prescaled=False):
     """Returns dqkv [B*S, 3H] (dq | dk | dv), the layout the fused QKV projection's backward consumes."""
     H = nheads * 64
     if dqkv is None:
@@ -243,7 +247,7 @@ def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_m
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     delta = workspace("attn_delta", B * nheads * S, q.device)
     corr, o_soft = corr if corr is not None else (None, None)
-    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft)
+    a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft, q_prescaled)
     a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
     a.ld_do, a.ld_dq, a.ld_dk, a.ld_dv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
     check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd")
@@ -301,15 +305,18 @@ def cast_weight(w, dtype, *, want_t=True, want_n=True, out_n=None, out_t=None):
 
 
 def make_cast_descs(entries, device):
-    """entries: list of (src f32 [R,C], dst|None, dst_t|None).  Returns a device uint8 tensor holding the C descriptor table."""
+    """entries: list of (src f32 [R,C], dst|None, dst_t|None[, scale_n]).  scale_n multiplies the values written to dst only (the transposed
+    copy stays unscaled): the attention pre-scale of the q rows.  Returns a device uint8 tensor holding the C descriptor table."""
     import struct
     buf = bytearray()
-    for src, dst, dst_t in entries:
+    for ent in entries:
+        src, dst, dst_t = ent[:3]
+        scale_n = float(ent[3]) if len(ent) > 3 and ent[3] is not None else 1.0
         R, Cc = src.shape
         ref = dst if dst is not None else dst_t
-        buf += struct.pack("<QQQqqiiii", src.data_ptr(), dst.data_ptr() if dst is not None else 0, dst_t.data_ptr() if dst_t is not None else 0,
-                           dst.stride(0) if dst is not None else Cc, dst_t.stride(0) if dst_t is not None else R, R, Cc, dt(ref), 0)
-    tiles = max(((s.shape[0] + 31) // 32) * ((s.shape[1] + 31) // 32) for s, _, _ in entries)
+        buf += struct.pack("<QQQqqiiif", src.data_ptr(), dst.data_ptr() if dst is not None else 0, dst_t.data_ptr() if dst_t is not None else 0,
+                           dst.stride(0) if dst is not None else Cc, dst_t.stride(0) if dst_t is not None else R, R, Cc, dt(ref), scale_n)
+    tiles = max(((e[0].shape[0] + 31) // 32) * ((e[0].shape[1] + 31) // 32) for e in entries)
     return torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone().to(device), tiles
 
 

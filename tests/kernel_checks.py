@@ -241,11 +241,24 @@ def _attn_ref(q, k, v, mask, mode, scale):
     return torch.einsum("bhqk,bhkd->bhqd", p, v)
 
 
-def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True, ref_style_mask=False):
+def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True, ref_style_mask=False, pre=False, spike=0.0):
     """ref_style_mask: the values PreFormer really produces (models/tav.py:383-397): {0,-65504} text, {65505,1} audio,
-    {0} video.  The rank-1 term then dwarfs softmax(s)v, so the check is against an fp64 reference."""
+    {0} video.  The rank-1 term then dwarfs softmax(s)v, so the check is against an fp64 reference.
+    pre: the q_prescaled convention of tav_attn_args (q holds q * scale * log2(e)); the reference sees the SAME rounded values divided
+    by the factor, and dq is still the gradient w.r.t. the unscaled q.
+    spike: scale factor on a few late (and one early) key rows, so a tile's maximum jumps past the running reference exponent by far
+    more than the lazy-rescale threshold of the forward kernel -- the rare branch gets its own test (and an fp64 reference)."""
     H = nh * 64
     qkv = _rnd(B * S, 3 * H, dtype=dtype, seed=20 + mode)
+    if spike:
+        qkv = qkv.float()
+        for row in {min(S - 1, 3), S // 2, max(0, S - 40), S - 1}:
+            qkv.view(B, S, 3 * H)[:, row, H:2 * H] *= spike
+        qkv = qkv.to(dtype)
+    c2 = ops.ATTN_Q_PRESCALE
+    if pre:
+        qkv = qkv.clone()
+        qkv[:, :H] = (qkv[:, :H].float() * c2).to(dtype)
     mask = None
     if mode == 1:
         mask = torch.zeros(B, S, device=DEV)
@@ -261,29 +274,32 @@ def check_attention(dtype, mode, B=2, S=200, nh=3, bwd=True, ref_style_mask=Fals
             mask[:, S // 4: S // 4 + S // 2] = 65505.0      # valid audio frames
             mask[0, S // 4 + S // 2 - 20: S // 4 + S // 2] = 1.0   # padded audio frames of row 0
     q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-    o, lse, corr = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode)
+    o, lse, corr = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre)
 
-    rdt = torch.float64 if ref_style_mask else torch.float32
+    rdt = torch.float64 if (ref_style_mask or spike) else torch.float32
 
-    def heads(t):
-        return t.to(rdt).reshape(B, S, nh, 64).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    def heads(t, div=1.0):
+        return (t.to(rdt) / div).reshape(B, S, nh, 64).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
 
-    qr, kr, vr = heads(q), heads(k), heads(v)
+    qr, kr, vr = heads(q, c2 if pre else 1.0), heads(k), heads(v)
     o_ref = _attn_ref(qr, kr, vr, mask.to(rdt) if mask is not None else None, mode, 0.125)
     tol = 2e-2 if dtype == torch.bfloat16 else 5e-5
-    rs = [_res(f"attn.fwd[{dtype},mode{mode},S{S},ref{int(ref_style_mask)}]", o, o_ref.permute(0, 2, 1, 3).reshape(B * S, H), tol)]
+    tag = f"{dtype},mode{mode},S{S},ref{int(ref_style_mask)},pre{int(pre)},spike{spike:g}"
+    rs = [_res(f"attn.fwd[{tag}]", o, o_ref.permute(0, 2, 1, 3).reshape(B * S, H), tol)]
+    lse_ref = torch.logsumexp(torch.einsum("bhqd,bhkd->bhqk", qr.detach(), kr.detach()) * 0.125 + (mask.to(rdt)[:, None, None, :] if mode == 1 else 0.0), dim=-1)
+    rs.append(_res(f"attn.lse[{tag}]", lse, lse_ref, 2e-2 if dtype == torch.bfloat16 else 1e-5))
     if bwd:
         do = _rnd(B * S, H, dtype=dtype, seed=30 + mode)
         o_ref.backward(do.to(rdt).reshape(B, S, nh, 64).permute(0, 2, 1, 3))
-        dqkv = ops.attn_bwd(q, k, v, o, do, lse, corr, B, S, nh, key_mask=mask, mask_mode=mode)
+        dqkv = ops.attn_bwd(q, k, v, o, do, lse, corr, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre)
 
         def flat(t):
             return t.permute(0, 2, 1, 3).reshape(B * S, H)
 
         tolb = (6e-2 if mode == 2 else 3e-2) if dtype == torch.bfloat16 else 1e-4
-        rs.append(_res(f"attn.dq[{dtype},mode{mode}]", dqkv[:, :H], flat(qr.grad), tolb))
-        rs.append(_res(f"attn.dk[{dtype},mode{mode}]", dqkv[:, H:2 * H], flat(kr.grad), tolb))
-        rs.append(_res(f"attn.dv[{dtype},mode{mode}]", dqkv[:, 2 * H:], flat(vr.grad), tolb))
+        rs.append(_res(f"attn.dq[{tag}]", dqkv[:, :H], flat(qr.grad), tolb))
+        rs.append(_res(f"attn.dk[{tag}]", dqkv[:, H:2 * H], flat(kr.grad), tolb))
+        rs.append(_res(f"attn.dv[{tag}]", dqkv[:, 2 * H:], flat(vr.grad), tolb))
     return rs
 
 
@@ -557,6 +573,19 @@ def all_checks():
         out.append(lambda d=dtype: check_attention(d, 1, B=1, S=512, nh=2))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=3136, nh=1))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=499, nh=2))
+        # tav_attn_args.q_prescaled (what the engine's layers run): every mask mode, the ragged / single-tile / long cases, the reference-style
+        # post-softmax mask, and key spikes that force the forward kernel's lazy rescale late in the key loop (moderate and extreme jumps)
+        for mode in (0, 1, 2):
+            out.append(lambda d=dtype, m=mode: check_attention(d, m, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=64, nh=1, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 0, B=2, S=1, nh=2, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=3136, nh=1, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 0, B=2, S=1464, nh=2, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 2, B=2, S=481, nh=12, ref_style_mask=True, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 0, B=2, S=328, nh=2, pre=True, spike=6.0))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=328, nh=2, pre=True, spike=300.0))
+        out.append(lambda d=dtype: check_attention(d, 2, B=1, S=300, nh=2, pre=True, spike=40.0))
+        out.append(lambda d=dtype: check_attention(d, 0, B=1, S=328, nh=2, spike=40.0))
         out.append(lambda d=dtype: check_layernorm(d))
         out.append(lambda d=dtype: check_layernorm(d, W=512, act=1))
         out.append(lambda d=dtype: check_layernorm(d, W=1024))

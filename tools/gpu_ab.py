@@ -37,18 +37,19 @@ def rnd(*s, dtype=torch.bfloat16):
 
 tag = os.path.basename(os.environ.get("TAV_LIB", "libtavhip.so"))
 if "attn" in what:
-    for (name, S, mode) in [("video", 1464, 0), ("fusion", 481, 2), ("audio", 249, 0), ("text", 128, 1)]:
-        nh, H = 12, 768
-        qkv = rnd(B * S, 3 * H)
-        mask = torch.zeros(B, S, device=dev) if mode else None
-        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        lo, med = timeit(lambda: ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode))
-        fl = 4 * B * nh * S * S * 64
-        print(f"[{tag}] attn_fwd {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
-        o, lse, aux = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode)
-        do = rnd(B * S, H)
-        lo, med = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, aux if mode == 2 else None, B, S, nh, key_mask=mask, mask_mode=mode))
-        print(f"[{tag}] attn_bwd {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2.5 * fl / lo / 1e6:7.1f} TF")
+    for pre in (False, True):         # q_prescaled: the convention the engine's layers use (tav_attn_args.q_prescaled)
+        for (name, S, mode) in [("video", 1464, 0), ("fusion", 481, 2), ("audio", 249, 0), ("text", 128, 1)] + ([("video-L", 2927, 0)] if os.environ.get("TAV_ATTN_LONG") else []):
+            nh, H = 12, 768
+            qkv = rnd(B * S, 3 * H)
+            mask = torch.zeros(B, S, device=dev) if mode else None
+            q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            lo, med = timeit(lambda: ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre))
+            fl = 4 * B * nh * S * S * 64
+            print(f"[{tag}] attn_fwd pre{int(pre)} {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {fl / lo / 1e6:7.1f} TF")
+            o, lse, aux = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre)
+            do = rnd(B * S, H)
+            lo, med = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, aux if mode == 2 else None, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre))
+            print(f"[{tag}] attn_bwd pre{int(pre)} {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2.5 * fl / lo / 1e6:7.1f} TF")
 if "gemm" in what:
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
                             ("video ffn2", B * 1464, 768, 3072), ("fusion qkv", B * 481, 2304, 768), ("audio ffn1", B * 249, 3072, 768),
