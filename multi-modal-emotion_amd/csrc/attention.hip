@@ -153,6 +153,48 @@ TAV_DEV void row_frags_gload(uint4* f, const char* base, long ld_bytes, int r, i
     for (int s = 0; s < HD<T>::NSD; ++s) f[s] = *reinterpret_cast<const uint4*>(base + (long)r * ld_bytes + (4 * s + g) * 16);
 }
 
+// LDS-DMA staging of two 64-row x 64-element bf16 tiles (A, B) of one (batch, head) slice into swizzled row images (HD<bf16>::row_off:
+// linear per 8 rows, so one DMA instruction fills 8 rows x 8 slots with the XOR applied to the SOURCE chunk a lane fetches).  Wave w fills
+// rows [16w, 16w + 16) of both images.  The lane offsets are constants of the kernel and the tile walks on the SCALAR bases: a regular
+// tile costs no vector instruction for its addresses.  RAGGED (the last tile when S % 64 != 0): rows past S-1 step back to row S-1 --
+// finite data; the consumer gives those rows / keys weight zero (-inf logits).
+struct PairDma {
+    const char* a; const char* b;
+    unsigned lda_b, ldb_b;             // bytes per row
+    unsigned offa[2], offb[2];
+    unsigned lds_a, lds_b;             // LDS byte addresses of this wave's 16 rows in slot 0 (wave-uniform)
+    int S, wave;
+    TAV_DEV void init(const char* a_, const char* b_, long lda_bytes, long ldb_bytes, int S_, const void* lds_img_a, const void* lds_img_b, int tid) {
+        a = a_; b = b_; lda_b = (unsigned)lda_bytes; ldb_b = (unsigned)ldb_bytes; S = S_;
+        const int lane = tid & 63;
+        wave = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+            const int ch = slot ^ (((row >> 1) & 3) << 1);
+            offa[j] = (unsigned)row * lda_b + (unsigned)(ch * 16);      // (32-bit: the host checks that a slice fits)
+            offb[j] = (unsigned)row * ldb_b + (unsigned)(ch * 16);
+        }
+        lds_a = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_a) + wave * 16 * 128);
+        lds_b = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_b) + wave * 16 * 128);
+    }
+    template <bool RAGGED> TAV_DEV void issue(int t, unsigned slot_bytes) const {
+        const char* ab = a + (size_t)t * 64u * lda_b;
+        const char* bb = b + (size_t)t * 64u * ldb_b;
+        unsigned oa[2] = {offa[0], offa[1]}, ob[2] = {offb[0], offb[1]};
+        if constexpr (RAGGED) {
+            int ln = threadIdx.x & 63;
+            asm volatile("" : "+v"(ln));                 // (re-materialised here: nothing of this is hoisted above the loop and kept live)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int over = t * 64 + wave * 16 + j * 8 + (ln >> 3) - (S - 1);
+                if (over > 0) { oa[j] -= (unsigned)over * lda_b; ob[j] -= (unsigned)over * ldb_b; }
+            }
+        }
+        glds16_x4(ab, bb, oa[0], oa[1], ob[0], ob[1], lds_a + slot_bytes, lds_b + slot_bytes);
+    }
+};
+
 // ================================================================================================= forward
 // ablation switches for the forward kernel (tools/ab_build.sh; timing experiments only, results are wrong with any of them set)
 #ifdef TAV_ABL_ATT_NOMFMA
@@ -261,36 +303,10 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
     // DMA geometry: wave w fills rows [16w, 16w + 16) of both images, 8 rows per instruction; lane -> (row, slot), source chunk = slot ^ swizzle.
     // The lane offsets are constants of the kernel; the tile walks on the SCALAR base (one s_add per operand), so a regular tile costs no
     // vector instruction for its addresses.  Only the ragged last tile clamps rows past S (to row S-1: finite data, their scores are -inf).
-    unsigned dk_off[2], dv_off[2];
-    unsigned lds_k = 0, lds_v = 0;
-    if constexpr (DMA) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
-            const int ch = slot ^ (((row >> 1) & 3) << 1);
-            dk_off[j] = (unsigned)row * (unsigned)(p.ld_k * ES) + (unsigned)(ch * 16);      // (32-bit: the host checks the slice fits)
-            dv_off[j] = (unsigned)row * (unsigned)(p.ld_v * ES) + (unsigned)(ch * 16);
-        }
-        lds_k = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 16 * H::ROWB);
-        lds_v = lds_k + KROW_B;
-    }
-    // DMA of tile t into slot buf.  RAGGED (the last tile when S is not a multiple of 64): rows past S-1 step back to row S-1 (finite data;
-    // their scores get -inf).  Two instantiations, so the regular tiles carry neither the clamp nor its lane arithmetic.
+    PairDma kv;
+    if constexpr (DMA) kv.init(Kb, Vb, p.ld_k * ES, p.ld_v * ES, S, smem, smem + KROW_B, tid);
     auto dma = [&](int t, int buf, auto ragged_tag) __attribute__((always_inline)) {
-        const char* kb = Kb + (size_t)t * kstep_b;
-        const char* vb = Vb + (size_t)t * vstep_b;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned ok = dk_off[j], ov = dv_off[j];
-            if constexpr (decltype(ragged_tag)::value) {
-                int ln = lane;
-                asm volatile("" : "+v"(ln));                 // (re-materialised here: nothing of this is hoisted above the loop and kept live)
-                const int over = t * BKV + wave * 16 + j * 8 + (ln >> 3) - (S - 1);
-                if (over > 0) { ok -= (unsigned)over * (unsigned)(p.ld_k * ES); ov -= (unsigned)over * (unsigned)(p.ld_v * ES); }
-            }
-            glds16_s(kb, ok, lds_k + buf * BUF_B + j * 1024);
-            glds16_s(vb, ov, lds_v + buf * BUF_B + j * 1024);
-        }
+        kv.template issue<decltype(ragged_tag)::value != 0>(t, (unsigned)(buf * BUF_B));
     };
     auto gload = [&](int t) {
         if constexpr (!DMA) {
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                 else corr_part += cm[key] * ET<T>::ld(reinterpret_cast<const T*>(Vnat + key * H::PITCH_N) + d);
             }
         }
-        if constexpr (NEXT != 0 && !ATT_ABL_NOGLOAD) lstore(t + 1, nxt);
+        if constexpr (NEXT != 0 && !ATT_ABL_NOGLOAD && (MODE != 0 || NEXT == 2 || !DMA)) lstore(t + 1, nxt);   // (unmasked: only the last tile has per-key terms)
         if constexpr (DMA) wait_vmcnt0();                     // tile t+1 has landed
         if (!ATT_ABL_NOBAR) __syncthreads();
     };
@@ -538,30 +554,6 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
     }
 }
 
-// ================================================================================================= backward: delta
-// delta[b][h][q] = sum_d dO[q][d] * (softmax(s) v)[q][d]   (mode 2 reads the o_soft copy, never o - corr)
-template <typename T, int MODE>
-__global__ void attn_bwd_delta_kernel(const AttnP p) {
-    // delta[b][head][s] = sum_d dO[b,s,head,d] * O[b,s,head,d] (O = the softmax-only part under mask mode 2).  16 lanes per (token, head):
-    // each lane multiplies 4 elements (one 8-B / 16-B load per tensor instead of a 2-B one) and the 16 partial sums meet in 4 DPP shuffles.
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long pair = gid >> 4;                              // (token, head) index, head fastest
-    const int q = (int)(gid & 15);
-    const long total = (long)p.B * p.S * p.nh;
-    const bool live = pair < total;
-    const long pr = live ? pair : total - 1;
-    const int head = (int)(pr % p.nh);
-    const long bs = pr / p.nh;
-    const int b = (int)(bs / p.S), s = (int)(bs - (long)b * p.S);
-    const T* osrc = reinterpret_cast<const T*>(MODE == 2 ? p.o_soft : p.o);
-    const f32x4 o = ld4(osrc + bs * p.ld_o + head * 64 + 4 * q);
-    const f32x4 d = ld4(reinterpret_cast<const T*>(p.dout) + bs * p.ld_do + head * 64 + 4 * q);
-    float v = (o[0] * d[0] + o[1] * d[1]) + (o[2] * d[2] + o[3] * d[3]);
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (live && q == 0) p.delta[((long)b * p.nh + head) * p.S + s] = v;
-}
-
 // ================================================================================================= backward: dK, dV
 // query-tile height of the dK/dV kernel: 64 for bf16 (half as many barriers and staging round trips per MFMA as 32), 32 for
 // f32 (register budget)
@@ -579,6 +571,7 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T>(), NQT = BQ / 16;
     constexpr int NCH = BQ * H::ROWCH / 256;
+    constexpr bool DMA = (ES == 2) && TAV_ATT_DMA && BQ == 64;   // bf16: Q / dO tiles by LDS-DMA (PairDma: 64-row tiles); f32: register staging
     constexpr int ROW_B = BQ * H::ROWB, NAT_B = H::DUAL ? 0 : BQ * H::PITCH_N;
     constexpr int BUF_B = 2 * ROW_B + 2 * NAT_B + 2 * BQ * 4;   // Qrow, dOrow, [Qnat, dOnat: f32 only], lse, delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -623,12 +616,30 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
     uint4 rq[NCH], rdo[NCH];
     float r_lse = 0.f, r_delta = 0.f;
     unsigned q_off0[NCH], q_max[NCH], do_off0[NCH], do_max[NCH];
-    tile_addr_init<T, BQ>(q_off0, q_max, p.ld_q * ES, S, tid);
-    tile_addr_init<T, BQ>(do_off0, do_max, p.ld_do * ES, S, tid);
+    if constexpr (!DMA) {
+        tile_addr_init<T, BQ>(q_off0, q_max, p.ld_q * ES, S, tid);
+        tile_addr_init<T, BQ>(do_off0, do_max, p.ld_do * ES, S, tid);
+    }
     const unsigned qstep_b = (unsigned)(BQ * p.ld_q * ES), dostep_b = (unsigned)(BQ * p.ld_do * ES);
+    PairDma qd;
+    if constexpr (DMA) qd.init(Qb, dOb, p.ld_q * ES, p.ld_do * ES, S, smem, smem + ROW_B, tid);
+    // lane constants of the fragment reads (bf16 row images; see attn_fwd_kernel): the row reads of Q and dO share one per k-step, the
+    // transposed reads one per d-tile
+    unsigned roff[NSD], toff[4];
+    if constexpr (ES == 2) {
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) { roff[s] = (unsigned)H::row_off(i, 4 * s + g); asm volatile("" : "+v"(roff[s])); }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            toff[dt] = (unsigned)(H::row_off(4 * g + (i >> 2), 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1));
+            asm volatile("" : "+v"(toff[dt]));
+        }
+    }
     auto gload = [&](int t) {
-        tile_gload(rq, Qb, q_off0, q_max, t * qstep_b);
-        tile_gload(rdo, dOb, do_off0, do_max, t * dostep_b);
+        if constexpr (!DMA) {
+            tile_gload(rq, Qb, q_off0, q_max, t * qstep_b);
+            tile_gload(rdo, dOb, do_off0, do_max, t * dostep_b);
+        }
         if (tid < BQ) {                                   // raw loads only (see attn_fwd_kernel::gload)
             int q = t * BQ + tid;
             q = q < S ? q : S - 1;
@@ -638,13 +649,15 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
     };
     auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
-        tile_zero_pad<T, BQ>(rq, t * BQ, S, tid);
-        tile_zero_pad<T, BQ>(rdo, t * BQ, S, tid);
-        tile_lstore_row<T, BQ>(rq, base, tid);
-        tile_lstore_row<T, BQ>(rdo, base + ROW_B, tid);
-        if constexpr (!H::DUAL) {
-            tile_lstore_nat<T, BQ>(rq, base + 2 * ROW_B, tid);
-            tile_lstore_nat<T, BQ>(rdo, base + 2 * ROW_B + NAT_B, tid);
+        if constexpr (!DMA) {
+            tile_zero_pad<T, BQ>(rq, t * BQ, S, tid);
+            tile_zero_pad<T, BQ>(rdo, t * BQ, S, tid);
+            tile_lstore_row<T, BQ>(rq, base, tid);
+            tile_lstore_row<T, BQ>(rdo, base + ROW_B, tid);
+            if constexpr (!H::DUAL) {
+                tile_lstore_nat<T, BQ>(rq, base + 2 * ROW_B, tid);
+                tile_lstore_nat<T, BQ>(rdo, base + 2 * ROW_B + NAT_B, tid);
+            }
         }
         if (tid < BQ) {
             const bool ok = t * BQ + tid < S;
@@ -653,6 +666,7 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
             f[BQ + tid] = ok ? -r_delta : 0.f;                // dP accumulators start at -delta
         }
     };
+    if constexpr (DMA) { if (nqt == 1) qd.template issue<true>(0, 0u); else qd.template issue<false>(0, 0u); }
     gload(0); lstore(0, 0);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -660,11 +674,17 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
         for (int s = 0; s < NSD; ++s) { settle(kf[kt][s]); settle(vf[kt][s]); }
         settle(kadd[kt]); settle(cmk[kt]);
     }
+    if constexpr (DMA) wait_vmcnt0();
     __syncthreads();
 
-    for (int t = 0; t < nqt; ++t) {
+    // NEXT: 0 no prefetch, 1 regular, 2 the ragged last tile (DMA rows past S-1 repeat row S-1: finite, and their p is 0 through lse = -inf)
+    auto tile_body = [&](const int t, auto next_tag) __attribute__((always_inline)) {
+        constexpr int NEXT = decltype(next_tag)::value;
         const int cur = t & 1;
-        if (t + 1 < nqt) gload(t + 1);
+        if constexpr (NEXT != 0) {
+            if constexpr (DMA) qd.template issue<NEXT == 2>(t + 1, (unsigned)((cur ^ 1) * BUF_B));
+            gload(t + 1);
+        }
         const char* Qrow = smem + cur * BUF_B;
         const char* dOrow = Qrow + ROW_B;
         const char* Qnat = Qrow + 2 * ROW_B;
@@ -688,8 +708,14 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
         for (int s = 0; s < NSD; ++s)
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
-                const uint4 aq = *reinterpret_cast<const uint4*>(Qrow + H::row_off(16 * qt + i, 4 * s + g));
-                const uint4 ad = *reinterpret_cast<const uint4*>(dOrow + H::row_off(16 * qt + i, 4 * s + g));
+                uint4 aq, ad;
+                if constexpr (ES == 2) {
+                    aq = *reinterpret_cast<const uint4*>(Qrow + roff[s] + qt * 16 * H::ROWB);
+                    ad = *reinterpret_cast<const uint4*>(dOrow + roff[s] + qt * 16 * H::ROWB);
+                } else {
+                    aq = *reinterpret_cast<const uint4*>(Qrow + H::row_off(16 * qt + i, 4 * s + g));
+                    ad = *reinterpret_cast<const uint4*>(dOrow + H::row_off(16 * qt + i, 4 * s + g));
+                }
                 mma16<T>(aq, kf[0][s], sacc[qt][0]);
                 mma16<T>(aq, kf[1][s], sacc[qt][1]);
                 mma16<T>(ad, vf[0][s], dpacc[qt][0]);
@@ -728,23 +754,41 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 a1 = tile_kfrag<T>(dOrow, dOnat, ks * KSTEP, dt, lane);
+                uint4 a1, a2;
+                if constexpr (ES == 2) {                      // = frag_tr_rowimg(.., ks * KSTEP, dt, lane) with the lane part precomputed
+                    const char* t1 = dOrow + toff[dt] + ks * KSTEP * H::ROWB;
+                    const char* t2 = Qrow + toff[dt] + ks * KSTEP * H::ROWB;
+                    const uint2 lo1 = lds_read_tr16(t1), hi1 = lds_read_tr16(t1 + 16 * H::ROWB);
+                    const uint2 lo2 = lds_read_tr16(t2), hi2 = lds_read_tr16(t2 + 16 * H::ROWB);
+                    a1 = make_uint4(lo1.x, lo1.y, hi1.x, hi1.y);
+                    a2 = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                } else {
+                    a1 = tile_kfrag<T>(dOrow, dOnat, ks * KSTEP, dt, lane);
+                    a2 = tile_kfrag<T>(Qrow, Qnat, ks * KSTEP, dt, lane);
+                }
                 mma16<T>(a1, pb[0], dVt[dt][0]);
                 mma16<T>(a1, pb[1], dVt[dt][1]);
-                const uint4 a2 = tile_kfrag<T>(Qrow, Qnat, ks * KSTEP, dt, lane);
                 mma16<T>(a2, dsb[0], dKt[dt][0]);
                 mma16<T>(a2, dsb[1], dKt[dt][1]);
             }
         }
-        if (MODE == 2) {   // sum_q dO[q][d]  (rows past S were zero-filled)
+        if (MODE == 2) {   // sum_q dO[q][d]  (register staging zero-fills rows past S; the DMA repeats row S-1 there: skip them)
             const int d = tid & 63, rq8 = tid >> 6;
 #pragma unroll
-            for (int rr = 0; rr < BQ / 4; ++rr)
-                dosum_part += tile_elem<T>(dOrow, dOnat, rq8 * (BQ / 4) + rr, d);
+            for (int rr = 0; rr < BQ / 4; ++rr) {
+                const int row = rq8 * (BQ / 4) + rr;
+                const float v = tile_elem<T>(dOrow, dOnat, row, d);
+                dosum_part += (!DMA || qbase + row < S) ? v : 0.f;
+            }
         }
-        if (t + 1 < nqt) lstore(t + 1, cur ^ 1);
+        if constexpr (NEXT != 0) lstore(t + 1, cur ^ 1);
+        if constexpr (DMA) wait_vmcnt0();                     // tile t+1 has landed
         __syncthreads();
-    }
+    };
+    int t = 0;
+    for (; t + 2 < nqt; ++t) tile_body(t, std::integral_constant<int, 1>{});
+    if (t + 1 < nqt) { tile_body(t, std::integral_constant<int, 2>{}); ++t; }
+    tile_body(t, std::integral_constant<int, 0>{});
 
     if (MODE == 2) {
         red[wave * 64 + lane] = dosum_part;
@@ -775,6 +819,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
+    constexpr bool DMA = (ES == 2) && TAV_ATT_DMA;          // bf16: K / V tiles by LDS-DMA (PairDma), no staging registers; f32: register staging
     constexpr int ROW_B = BKV * H::ROWB, NAT_B = H::DUAL ? 0 : BKV * H::PITCH_N;
     constexpr int BUF_B = 2 * ROW_B + NAT_B + BKV * 4;   // Krow, Vrow, [Knat: f32 only], kadd
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -798,7 +843,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
         row_frags_gload<T>(dof[qt], dOb, p.ld_do * ES, q, S, g);
         if (q >= S) q = S - 1;
         lse_q[qt] = -p.lse[((long)b * p.nh + head) * S + q] * (PRE ? 1.4426950408889634f : 1.0f / p.scale);   // S accumulators start at -lse/scale (PRE: -lse*log2e), dP at -delta
-        delta_q[qt] = -p.delta[((long)b * p.nh + head) * S + q];           // (row constants as the initial accumulators)
+        // delta[q] = sum_d dO[q][d] * (softmax(s) v)[q][d], formed HERE (this kernel runs first and has the dO rows in registers anyway; the
+        // separate delta kernel of rounds 1-2 cost a launch and 33 us at batch 32) and written out for the dK/dV kernel.  Lane (g, i) holds
+        // chunks 4s + g of query i's rows: 16 of the 64 products; the four lane groups meet in two permlane swaps.
+        const char* Ob = (MODE == 2 ? p.o_soft : p.o) + ((long)b * S * p.ld_o + (long)head * 64) * ES;     // (mode 2: the softmax-only part, never o - corr)
+        uint4 of[NSD];
+        row_frags_gload<T>(of, Ob, p.ld_o * ES, q, S, g);
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) {
+            const uint32_t ow[4] = {of[s].x, of[s].y, of[s].z, of[s].w}, dw[4] = {dof[qt][s].x, dof[qt][s].y, dof[qt][s].z, dof[qt][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (ES == 2) {
+                    part = __builtin_fmaf(bf16_bits_to_f32(ow[e] & 0xffffu), bf16_bits_to_f32(dw[e] & 0xffffu), part);
+                    part = __builtin_fmaf(__uint_as_float(ow[e] & 0xffff0000u), __uint_as_float(dw[e] & 0xffff0000u), part);
+                } else part = __builtin_fmaf(__uint_as_float(ow[e]), __uint_as_float(dw[e]), part);
+            }
+        }
+        part = sum_over_row_groups(part);
+        delta_q[qt] = -part;                                               // (row constants as the initial accumulators)
+        if (g == 0 && q0 + 16 * qt + i < S) p.delta[((long)b * p.nh + head) * S + q] = part;
     }
     const float c2 = PRE ? 1.0f : p.scale * 1.4426950408889634f;
     f32x4 dQt[4][2];
@@ -809,12 +874,29 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
     uint4 rk[NCH], rv[NCH];
     float r_kadd = 0.f;
     unsigned k_off0[NCH], k_max[NCH], v_off0[NCH], v_max[NCH];
-    tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
-    tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    if constexpr (!DMA) {
+        tile_addr_init<T, BKV>(k_off0, k_max, p.ld_k * ES, S, tid);
+        tile_addr_init<T, BKV>(v_off0, v_max, p.ld_v * ES, S, tid);
+    }
     const unsigned kstep_b = (unsigned)(BKV * p.ld_k * ES), vstep_b = (unsigned)(BKV * p.ld_v * ES);
+    PairDma kv;
+    if constexpr (DMA) kv.init(Kb, Vb, p.ld_k * ES, p.ld_v * ES, S, smem, smem + ROW_B, tid);
+    // lane constants of the fragment reads (bf16 row images; see attn_fwd_kernel): row reads of K and V share one, the transposed K reads four
+    unsigned koff[NSD], ktoff[4];
+    if constexpr (ES == 2) {
+#pragma unroll
+        for (int s = 0; s < NSD; ++s) { koff[s] = (unsigned)H::row_off(i, 4 * s + g); asm volatile("" : "+v"(koff[s])); }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            ktoff[dt] = (unsigned)(H::row_off(4 * g + (i >> 2), 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1));
+            asm volatile("" : "+v"(ktoff[dt]));
+        }
+    }
     auto gload = [&](int t) {
-        tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
-        tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        if constexpr (!DMA) {
+            tile_gload(rk, Kb, k_off0, k_max, t * kstep_b);
+            tile_gload(rv, Vb, v_off0, v_max, t * vstep_b);
+        }
         if (MODE == 1 && tid < BKV) {                     // raw load only (see attn_fwd_kernel::gload)
             int key = t * BKV + tid;
             key = key < S ? key : S - 1;
@@ -823,12 +905,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
     };
     auto lstore = [&](int t, int buf) {
         char* base = smem + buf * BUF_B;
-        tile_lstore_row<T, BKV>(rk, base, tid);
-        tile_lstore_row<T, BKV>(rv, base + ROW_B, tid);
-        if constexpr (!H::DUAL) tile_lstore_nat<T, BKV>(rk, base + 2 * ROW_B, tid);
-        if (tid < BKV)
+        if constexpr (!DMA) {
+            tile_lstore_row<T, BKV>(rk, base, tid);
+            tile_lstore_row<T, BKV>(rv, base + ROW_B, tid);
+            if constexpr (!H::DUAL) tile_lstore_nat<T, BKV>(rk, base + 2 * ROW_B, tid);
+        }
+        if ((MODE == 1 || t == nkt - 1) && tid < BKV)     // (only the masked / ragged tiles read the per-key terms)
             reinterpret_cast<float*>(base + 2 * ROW_B + NAT_B)[tid] = (t * BKV + tid < S) ? (MODE == 1 ? r_kadd * 1.4426950408889634f : 0.f) : -INFINITY;
     };
+    if constexpr (DMA) { if (nkt == 1) kv.template issue<true>(0, 0u); else kv.template issue<false>(0, 0u); }
     gload(0); lstore(0, 0);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -836,11 +921,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
         for (int s = 0; s < NSD; ++s) { settle(qf[qt][s]); settle(dof[qt][s]); }
         settle(lse_q[qt]); settle(delta_q[qt]);
     }
+    if constexpr (DMA) wait_vmcnt0();
     __syncthreads();
 
-    for (int t = 0; t < nkt; ++t) {
+    // KADD: the tile has per-key additive terms (pre-softmax mask; -inf past S on the last tile).  NEXT: 0 none, 1 regular, 2 ragged prefetch.
+    auto tile_body = [&](const int t, auto kadd_tag, auto next_tag) __attribute__((always_inline)) {
+        constexpr bool KADD = decltype(kadd_tag)::value != 0;
+        constexpr int NEXT = decltype(next_tag)::value;
         const int cur = t & 1;
-        if (t + 1 < nkt) gload(t + 1);
+        if constexpr (NEXT != 0) {
+            if constexpr (DMA) kv.template issue<NEXT == 2>(t + 1, (unsigned)((cur ^ 1) * BUF_B));
+            gload(t + 1);
+        }
         const char* Krow = smem + cur * BUF_B;
         const char* Vrow = Krow + ROW_B;
         const char* Knat = Krow + 2 * ROW_B;
@@ -859,8 +951,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
         for (int s = 0; s < NSD; ++s)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const uint4 ak = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
-                const uint4 av = *reinterpret_cast<const uint4*>(Vrow + H::row_off(16 * kt + i, 4 * s + g));
+                uint4 ak, av;
+                if constexpr (ES == 2) {
+                    ak = *reinterpret_cast<const uint4*>(Krow + koff[s] + kt * 16 * H::ROWB);
+                    av = *reinterpret_cast<const uint4*>(Vrow + koff[s] + kt * 16 * H::ROWB);
+                } else {
+                    ak = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
+                    av = *reinterpret_cast<const uint4*>(Vrow + H::row_off(16 * kt + i, 4 * s + g));
+                }
                 mma16<T>(ak, qf[0][s], sacc[kt][0]);
                 mma16<T>(ak, qf[1][s], sacc[kt][1]);
                 mma16<T>(av, dof[0][s], dpacc[kt][0]);
@@ -868,7 +966,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
             }
         // p = exp2(c2 * S' + kadd);  dS^T (without the softmax scale, applied at the store) = p * dP'.  kadd is zero except under a
         // pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S).
-        if ((MODE == 1) || (t == nkt - 1)) {
+        if constexpr (KADD) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
@@ -896,14 +994,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint4 a = tile_kfrag<T>(Krow, Knat, ks * KSTEP, dt, lane);
+                uint4 a;
+                if constexpr (ES == 2) {                      // = frag_tr_rowimg(Krow, ks * KSTEP, dt, lane) with the lane part precomputed
+                    const char* kt_ = Krow + ktoff[dt] + ks * KSTEP * H::ROWB;
+                    const uint2 lo = lds_read_tr16(kt_), hi = lds_read_tr16(kt_ + 16 * H::ROWB);
+                    a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else a = tile_kfrag<T>(Krow, Knat, ks * KSTEP, dt, lane);
                 mma16<T>(a, dsb[0], dQt[dt][0]);
                 mma16<T>(a, dsb[1], dQt[dt][1]);
             }
         }
-        if (t + 1 < nkt) lstore(t + 1, cur ^ 1);
+        if constexpr (NEXT != 0) lstore(t + 1, cur ^ 1);
+        if constexpr (DMA) wait_vmcnt0();                     // tile t+1 has landed
         __syncthreads();
-    }
+    };
+    using K0 = std::integral_constant<int, (MODE == 1) ? 1 : 0>;
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile_body(t, K0{}, std::integral_constant<int, 1>{});
+    if (t + 1 < nkt) { tile_body(t, K0{}, std::integral_constant<int, 2>{}); ++t; }
+    tile_body(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});          // the last tile: -inf past S
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + i;
@@ -965,11 +1074,9 @@ template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, 
     return (int)hipGetLastError();
 }
 template <typename T, int MODE, bool PRE> static int launch_bwd(const AttnP& p, hipStream_t st) {
-    const long rows = (long)p.B * p.S * p.nh;
-    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, MODE>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, p);
     dim3 grid((p.S + 127) / 128, p.nh, p.B);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), dkdv_lds<T>(), st, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, p);        // also writes delta [B][nh][S]
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), dkdv_lds<T>(), st, p);    // reads it
     return (int)hipGetLastError();
 }
 template <typename T, bool PRE> static int dispatch_fwd(const AttnP& p, int mode, hipStream_t st) {

@@ -165,6 +165,21 @@ TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
                  : "v"(voff), "s"(sbase), "s"(lds_base)
                  : "memory");
 }
+// Four LDS-DMA instructions in ONE statement: two 16-row pieces (1 KiB apart in LDS) of each of two operands.  One M0 save / restore for
+// the group and the second piece's LDS address formed by s_add into M0: 15 scalar / vector-memory instructions instead of 4 x 5 + the
+// address adds (the attention kernels are bound by instructions ISSUED per SIMD, scalar ones included: profiles/r03_experiments.md).
+TAV_DEV void glds16_x4(const void* abase, const void* bbase, unsigned va0, unsigned va1, unsigned vb0, unsigned vb1, unsigned lds_a, unsigned lds_b) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+                 "s_add_u32 m0, %7, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, %8, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(va0), "v"(va1), "v"(vb0), "v"(vb1), "s"(abase), "s"(bbase), "s"(lds_a), "s"(lds_b)
+                 : "memory", "scc");
+}
 // Values loaded from global memory BEFORE a loop and consumed inside it: hipcc's waitcnt pass cannot tell how many younger loads
 // a conditional in-loop prefetch has put in flight, so it protects every in-loop use with `s_waitcnt vmcnt(0/1)` -- which drains
 // the prefetch issued a few instructions earlier and exposes the full memory latency on every tile.  settle() makes the register
@@ -195,6 +210,16 @@ TAV_DEV float max_over_row_groups(float v) {
     u = __float_as_uint(a);
     auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return vmax_raw(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+
+// sum over the same four lanes (two swaps, two adds; every lane ends with the total)
+TAV_DEV float sum_over_row_groups(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(a);
+    auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
 
 // exact-erf GELU (nn.GELU() default; reference utils/TAVFormer.py:398) and its derivative
