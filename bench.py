@@ -61,7 +61,8 @@ def fwd_gflop_per_utt(cfg, s_text=128, t_audio=80000):
     return (pre + model) / 1e9, n_fus
 
 GLOBAL_BATCH = 32                      # BASELINE.json metric: "... b=32, 1/2/4/8 MI355X"
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc", "traffic_per_launch.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc", "traffic_per_launch.json")
+HBM_PEAK_GBS = 8000.0                 # HBM3E, same guide (about 6300 GB/s is what a streaming copy reaches)
 
 
 def log(*a):
@@ -90,7 +91,7 @@ def parse_args():
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fwd+bwd only, batch 8)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fwd+bwd only, batch 8, preset A)")
     ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"],
                     help="bounded: b=1, 2 warm-ups, median of 5 (~25 s); full: BASELINE.md §3, b in {1, 8} (several minutes)")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
@@ -391,6 +392,40 @@ def main():
                 el, _, _ = timed(s8, args.steps)
                 secondary["batch_8"] = {"utterances_per_s": round(8 * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3),
                                         "note": "BASELINE.json configs[1]: same step at 8 utterances per GPU"}
+            if args.preset == "B" and args.dtype == "bf16" and os.environ.get("TAV_BENCH_PRESET_A", "1") == "1":
+                # the reference-faithful geometry (preset A: distilroberta 6 L + wav2vec2-large-xlsr 24 L / 1024 + videomae-base, what the
+                # reference's hard-coded from_pretrained names resolve to, models/tav.py:438,455-457) beside the headline, same global batch
+                cfg_a = C.preset("A")
+                torch.manual_seed(0)
+                pre_a, model_a = PreFormer(cfg_a), TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg_a)
+                synthetic.seeded_init_(pre_a, 1)
+                synthetic.seeded_init_(model_a, 2)
+                pre_a.to(dev)
+                model_a.to(dev)
+                inp_a, lab_a = synthetic.make_batch(cfg_a, b, seed=1234, device=dev)
+                gf_a, n_true_a = fwd_gflop_per_utt(cfg_a)
+                step_a = TrainStep(model_a, pre_a, CrossEntropyLoss(), lr=1e-6, weight_decay=1e-4, clip=1.0)
+
+                def stepA():
+                    ls = step_a.forward_backward(inp_a, lab_a, check="val", epoch=0, n_visual_true=n_true_a)
+                    step_a.update()
+                    return ls
+                for _ in range(2):
+                    stepA()
+                torch.cuda.synchronize()
+                engine.bump_weight_epoch()
+                step_a.opt.zero_grad()
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=work_stream):
+                    loss_a = stepA()
+                ga.replay()
+                el, _, _ = timed(lambda: (ga.replay(), loss_a)[1], args.steps)
+                secondary["preset_A"] = {"utterances_per_s": round(b * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3),
+                                         "workload": f"preset A ({describe(cfg_a)}), global batch {b}, same input shapes, {gf_a:.1f} GFLOP forward per utterance",
+                                         "mfma_util_whole_step": round(3 * gf_a * 1e9 * b / (el / args.steps) / (MFMA_PEAK_BF16_TFLOPS * 1e12), 4),
+                                         "final_loss": round(float(loss_a), 5)}
+                del ga, step_a, pre_a, model_a, inp_a, lab_a
+                torch.cuda.empty_cache()
         except Exception as e:
             capture_failed(e)
         log(f"[rank {rank}] secondary: {secondary}")
@@ -407,7 +442,7 @@ def main():
         ms_default = runtime.multistream[0]
         runtime.multistream[0] = False
         eager_step()                                         # shapes may have changed (secondary batch): re-warm
-        ops.profile_start("gemm_nt")
+        ops.profile_start(("gemm_nt", "gemm_tn", "attn", "ln"))
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
@@ -432,10 +467,31 @@ def main():
                                f"{rec.get('per_gpu_batch')}, now {kernel_source_hash()} / {b}")
         except Exception:
             pass
+        # the other kernel families, timed in the same instrumented pass (HIP event pair per launch, each launch alone on the device):
+        # attention (forward 4 B h S^2 d, backward 10 B h S^2 d algorithmic FLOPs: the backward EXECUTES 14 -- it recomputes S and dP in both of
+        # its kernels to stay free of atomics), the weight-gradient GEMMs (2 tokens N1 N2) and the LayerNorm kernels (HBM-bound: bytes read + written once)
+        fams = {}
+        for name, d in getattr(ops.profile_stop, "families", {}).items():
+            if name == "gemm_nt" or not d["launches"]:
+                continue
+            if name == "ln":
+                a_ = d["bytes"] / max(d["secs"], 1e-9) / 1e9
+                fams["layernorm"] = {"kernel": "tav::ln_fwd_kernel / ln_bwd_kernel", "bound": "hbm", "achieved": round(a_, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(a_ / HBM_PEAK_GBS, 4)}
+            else:
+                a_ = d["work"] / max(d["secs"], 1e-9) / 1e12
+                fams[{"attn": "attention", "gemm_tn": "gemm_tn"}[name]] = {
+                    "kernel": {"attn": "tav::attn_fwd_kernel / attn_bwd_dq_kernel / attn_bwd_dkdv_kernel", "gemm_tn": "tav::gemm_tn_grouped_big_kernel / gemm_tn_grouped_kernel / gemm_tn_kernel"}[name],
+                    "bound": "mfma", "achieved": round(a_, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a_ / MFMA_PEAK_BF16_TFLOPS, 4)}
+            f_ = fams["layernorm" if name == "ln" else {"attn": "attention", "gemm_tn": "gemm_tn"}[name]]
+            f_.update({"launches_per_step": d["launches"] // 2, "avg_launch_us": round(d["secs"] / d["launches"] * 1e6, 2), "serial_ms_per_step": round(d["secs"] / 2 * 1e3, 3),
+                       "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"])})
         roof = {"kernel": f"tav::gemm_nt_kernel<{args.dtype},*>", "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(getattr(ops.profile_stop, "algorithmic_bytes", 0.0) / max(launches, 1)), "launches_per_step": launches // 2,
                 "avg_launch_us": round(secs / launches * 1e6, 2), "serial_ms_per_step": round(secs / 2 * 1e3, 3)}
+        if fams:
+            roof["families"] = fams
 
     cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

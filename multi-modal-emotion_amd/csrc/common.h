@@ -165,6 +165,15 @@ TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
                  : "v"(voff), "s"(sbase), "s"(lds_base)
                  : "memory");
 }
+// The GEMM main loops' form: no save / restore of M0.  That is legal only
+// because nothing the compiler generates for these kernels reads or writes M0 (gfx9+ DS instructions do not use it); tools/check_isa.py
+// verifies it on the built library (every M0 write is one of these and is followed by its LDS-DMA; no other M0 user exists).  Together with a
+// scalar source base that the CALLER advances per K-tile (voff stays a lane constant) a piece costs 4 instructions (one compiler-made scalar add for the LDS address) instead of 7: the GEMM
+// main loops are bound by instructions ISSUED per SIMD -- with the MFMAs removed they take the same time, with the DMA sequences removed
+// 21 % less (profiles/r02_experiments.md), which is the share of issue slots those sequences held.
+TAV_DEV void glds16_m0(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 // Four LDS-DMA instructions in ONE statement: two 16-row pieces (1 KiB apart in LDS) of each of two operands.  One M0 save / restore for
 // the group and the second piece's LDS address formed by s_add into M0: 15 scalar / vector-memory instructions instead of 4 x 5 + the
 // address adds (the attention kernels are bound by instructions ISSUED per SIMD, scalar ones included: profiles/r03_experiments.md).

@@ -114,9 +114,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     }
     const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_addr(sA) + wave * 8 * TM * 128);
     const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 8 * PB * 128);
-    auto stage_piece = [&](int pc, unsigned ko, int buf) {  // piece pc of the next K-tile image: TM pieces of A, then PB of B
+    // piece pc of the next K-tile image: TM pieces of A, then PB of B.  The K offset rides on the SCALAR operand base (one 64-bit scalar add
+    // per operand and K-tile); the lane offsets ga / gb never change, so a piece is {scalar add for the LDS address, M0, nop, DMA}.
+    auto stage_piece = [&](int pc, unsigned ko, int buf) {
+#ifdef TAV_NT_DMA_OLD
         if (pc < TM) glds16_s(Ab, ga[pc] + ko, ldsA + buf * TILE_A + pc * 1024);
         else glds16_s(Bb, gb[pc - TM] + ko, ldsB + buf * TILE_B + (pc - TM) * 1024);
+#else
+        if (pc < TM) glds16_m0(Ab + ko, ga[pc], ldsA + buf * TILE_A + pc * 1024);
+        else glds16_m0(Bb + ko, gb[pc - TM], ldsB + buf * TILE_B + (pc - TM) * 1024);
+#endif
     };
 
     f32x4 acc[TNW][TM];  // [tn][tm]
@@ -528,8 +535,8 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
             const unsigned ka = kt * strideA, kb = kt * strideB;
 #pragma unroll
             for (int j = 0; j < NINST; ++j) {
-                glds16_s(Ab0, offA[j] + ka, ldsA + buf * TILE_BYTES + j * 1024);
-                glds16_s(Bb0, offB[j] + kb, ldsB + buf * TILE_BYTES + j * 1024);
+                glds16_m0(Ab0 + ka, offA[j], ldsA + buf * TILE_BYTES + j * 1024);      // (K offset on the scalar base, no M0 save / restore: common.h)
+                glds16_m0(Bb0 + kb, offB[j], ldsB + buf * TILE_BYTES + j * 1024);
             }
         } else {                                                    // ragged last K-tile: ordinary loads, zero fill
 #pragma unroll 1
@@ -694,8 +701,8 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    glds16_s(Ab0, offA[h][j] + ka, lds0 + buf * STAGE + h * SUB + j * 1024);
-                    glds16_s(Bb0, offB[h][j] + kb, lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
+                    glds16_m0(Ab0 + ka, offA[h][j], lds0 + buf * STAGE + h * SUB + j * 1024);
+                    glds16_m0(Bb0 + kb, offB[h][j], lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
                 }
         } else {                                                    // ragged last K-tile: ordinary loads, zero fill
 #pragma unroll 1
@@ -727,8 +734,8 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
     // barrier they cost every wave of the CU ~1000 cycles of issue time at the same moment, with nothing on the matrix pipe
     auto stage_piece = [&](int pc, unsigned ka, unsigned kb, int buf) {
         const int h = (pc >> 1) & 1, j = pc >> 2;
-        if (pc & 1) glds16_s(Bb0, offB[h][j] + kb, lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
-        else glds16_s(Ab0, offA[h][j] + ka, lds0 + buf * STAGE + h * SUB + j * 1024);
+        if (pc & 1) glds16_m0(Bb0 + kb, offB[h][j], lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
+        else glds16_m0(Ab0 + ka, offA[h][j], lds0 + buf * STAGE + h * SUB + j * 1024);
     };
     if (nk > 0) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {

@@ -219,6 +219,13 @@ def _c(t):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+_BWD_LP_OUT = os.environ.get("TAV_BWD_LP_OUT", "1") == "1"
+
+
+def _DGRAD_OUT(pol):
+    return torch.float32 if (pol.f32 or not _BWD_LP_OUT) else pol.lp
+
+
 # ---------------------------------------------------------------------------------------------- encoder layer
 class LayerSpec:
     def __init__(self, B, S, nheads, eps, pre_ln, mask_mode=0, branch=None):
@@ -309,7 +316,10 @@ class EncoderLayerFn(torch.autograd.Function):
         # FFN
         du = ops.gemm_nt(dy2_lp, w2_t, gelu_in=u, act=4)
         if spec.pre_ln:
-            dc = ops.gemm_nt(du, w1_t, out_dtype=torch.float32)
+            # dgrad outputs that ONLY feed a LayerNorm backward (pre-LN layers) leave the GEMM in the operand dtype: LN backward takes the
+            # rounded values straight into its f32 row arithmetic and adds the f32 residual gradient there, so the residual stream itself
+            # stays f32 -- and the GEMM epilogue writes, and LN backward reads, half the bytes (TAV_BWD_LP_OUT=0: f32 as in round 2)
+            dc = ops.gemm_nt(du, w1_t, out_dtype=_DGRAD_OUT(pol))
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
             dy1, dy1_lp = g1, g1_lp
         else:
@@ -320,7 +330,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
                             B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
         if spec.pre_ln:
-            da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=torch.float32)
+            da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=_DGRAD_OUT(pol))
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON and not pol.f32)
             if not pol.f32:
                 _hint_set(g0, g0_lp)
@@ -458,7 +468,17 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         return (g0, None, None, None, None, *grads)
 
 
+_F32_BRANCHES = tuple(b for b in os.environ.get("TAV_F32_BRANCHES", "").split(",") if b)      # error attribution only (tools/gpu_bf16_attrib.py)
+_f32_ctx = []
+
+
 def encoder_layer(ectx, spec, x, x_lp, key_mask, params):
+    if _F32_BRANCHES and spec.branch in _F32_BRANCHES and not ectx.pol.f32:
+        # attribution experiment: this stack's transformer layers run under the fp32 policy inside an otherwise bf16 step
+        if not _f32_ctx:
+            _f32_ctx.append(Ctx("fp32"))
+        x2, _ = EncoderLayerFn.apply(x, None, key_mask, _f32_ctx[0], spec, *params)
+        return x2, None
     fn = EncoderLayerFp8Fn if (ectx.pol.fp8 and spec.branch in ectx.pol.fp8_stacks) else EncoderLayerFn
     x2, x2_lp = fn.apply(x, x_lp, key_mask, ectx, spec, *params)
     return x2, (x2_lp if x2_lp.numel() else None)

@@ -30,17 +30,41 @@ def clear_workspaces():
 _prof = None
 
 
-def profile_start(kind):
+def profile_start(kinds):
+    """kinds: one family name or several of "gemm_nt", "gemm_tn", "attn", "ln" (every launch of those families gets a HIP event pair)."""
     global _prof
-    _prof = {"kind": kind, "ev": []}
+    _prof = {"kinds": {kinds} if isinstance(kinds, str) else set(kinds), "ev": []}
+
+
+def _prof_launch(family, select, work, nbytes, launch):
+    """Run `launch()`; while a profile of `family` is active, bracket it with a HIP event pair on the launch stream and record its
+    algorithmic work (FLOPs for the MFMA-bound families, 0 for the HBM-bound one) and algorithmic bytes."""
+    if _prof is not None and family in _prof["kinds"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        _prof["ev"].append((e0, e1, float(work), select, float(nbytes), family))
+    else:
+        launch()
 
 
 def profile_stop(select="bf16"):
-    """-> (algorithmic FLOPs, seconds inside the kernels, launches) of the launches with `select` operands ("bf16" / "fp8") since profile_start()."""
+    """-> (algorithmic FLOPs, seconds inside the kernels, launches) of the gemm_nt launches with `select` operands ("bf16" / "fp8") since
+    profile_start(); profile_stop.families = {family: {"work", "bytes", "secs", "launches"}} for every profiled family (all operand types)."""
     global _prof
     torch.cuda.synchronize()
-    ev, _prof = [e for e in _prof["ev"] if e[3] == select], None
-    secs = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in ev) * 1e-3
+    allev, _prof = _prof["ev"], None
+    fam = {}
+    for e0, e1, work, sel, nbytes, family in allev:
+        d = fam.setdefault(family, {"work": 0.0, "bytes": 0.0, "secs": 0.0, "launches": 0})
+        d["work"] += work
+        d["bytes"] += nbytes
+        d["secs"] += e0.elapsed_time(e1) * 1e-3
+        d["launches"] += 1
+    profile_stop.families = fam
+    ev = [e for e in allev if e[5] == "gemm_nt" and e[3] == select]
+    secs = sum(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
     profile_stop.algorithmic_bytes = sum(e[4] for e in ev)          # operands + output once each (the minimum the launches could move)
     return sum(e[2] for e in ev), secs, len(ev)
 
@@ -79,19 +103,13 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
         assert resid.dtype == torch.float32
     if gelu_in is not None:
         assert gelu_in.dtype == (torch.bfloat16 if a.dtype == torch.float8_e4m3fn else a.dtype)
-    if _prof is not None and _prof["kind"] == "gemm_nt" and a.dtype in (torch.bfloat16, torch.float8_e4m3fn):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
-        e1.record()
-        nz = max(nzb, 1) * max(nzg, 1)
-        _prof["ev"].append((e0, e1, 2.0 * M * N * K * nz, "bf16" if a.dtype == torch.bfloat16 else "fp8",
-                            # operands, output and every epilogue side tensor once each: the minimum the launch could move
-                            nz * ((M * K + N * K) * a.element_size() + M * N * ((4 if out_dtype == torch.float32 else 2) * (2 if want_pre else 1)
-                                                                                + (4 if resid is not None else 0) + (2 if gelu_in is not None else 0)
-                                                                                + ((4 if out_dtype == torch.float32 else 2) if accumulate else 0)))))
-    else:
-        check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt")
+    nz = max(nzb, 1) * max(nzg, 1)
+    osz = 4 if out_dtype == torch.float32 else 2
+    # operands, output and every epilogue side tensor once each: the minimum the launch could move
+    nbytes = nz * ((M * K + N * K) * a.element_size() + M * N * (osz * (2 if want_pre else 1) + (4 if resid is not None else 0)
+                                                                 + (2 if gelu_in is not None else 0) + (osz if accumulate else 0)))
+    sel = "bf16" if a.dtype == torch.bfloat16 else ("fp8" if a.dtype == torch.float8_e4m3fn else "f32")
+    _prof_launch("gemm_nt", sel, 2.0 * M * N * K * nz, nbytes, lambda: check(lib().tav_gemm_nt(C.byref(g), stream()), "gemm_nt"))
     return (out, pre) if want_pre else out
 
 
@@ -120,7 +138,9 @@ def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb
         bpart = workspace("tn_bias", ns.value * N1, a.device)
         g.dbias, g.bias_partials = ptr(dbias), ptr(bpart)
     assert a.dtype == b.dtype
-    check(lib().tav_gemm_tn(C.byref(g), stream()), "gemm_tn")
+    tokens = rows_per_batch * nbatch
+    _prof_launch("gemm_tn", "bf16" if a.dtype == torch.bfloat16 else "f32", 2.0 * tokens * N1 * N2, tokens * (N1 + N2) * a.element_size() + 4 * N1 * N2,
+                 lambda: check(lib().tav_gemm_tn(C.byref(g), stream()), "gemm_tn"))
     return (out, dbias) if want_bias else out
 
 
@@ -143,7 +163,10 @@ def gemm_tn_grouped(pairs, want_bias=True, flags=0):
         outs.append((dW, db))
     nbytes = lib().tav_gemm_tn_grouped_ws_bytes(probs, n, rows, dt(pairs[0][0]), flags)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=pairs[0][0].device) if nbytes > 0 else None
-    check(lib().tav_gemm_tn_grouped_ws(probs, n, rows, dt(pairs[0][0]), ptr(ws), nbytes, flags, stream()), "gemm_tn_grouped")
+    es = pairs[0][0].element_size()
+    _prof_launch("gemm_tn", "bf16" if dtype == torch.bfloat16 else "f32", sum(2.0 * rows * a.shape[1] * b.shape[1] for a, b in pairs),
+                 sum(rows * (a.shape[1] + b.shape[1]) * es + 4 * a.shape[1] * b.shape[1] for a, b in pairs),
+                 lambda: check(lib().tav_gemm_tn_grouped_ws(probs, n, rows, dt(pairs[0][0]), ptr(ws), nbytes, flags, stream()), "gemm_tn_grouped"))
     return outs
 
 
@@ -235,7 +258,9 @@ def attn_fwd(q, k, v, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, 
     corr = torch.empty(B, nheads, 64, dtype=torch.float32, device=q.device) if mask_mode == 2 else None
     o_soft = torch.empty_like(o) if mask_mode == 2 else None
     a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft, q_prescaled)
-    check(lib().tav_attn_fwd(C.byref(a), stream()), "attn_fwd")
+    es = q.element_size()
+    _prof_launch("attn", "bf16" if q.dtype == torch.bfloat16 else "f32", 4.0 * B * nheads * S * S * 64, 4 * B * S * H * es,      # Q, K, V, O once
+                 lambda: check(lib().tav_attn_fwd(C.byref(a), stream()), "attn_fwd"))
     return o, lse, (corr, o_soft)
 
 
@@ -250,7 +275,9 @@ def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_m
     a = _attn_args(q, k, v, o, B, S, nheads, key_mask, lse, corr, mask_mode, scale, o_soft, q_prescaled)
     a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
     a.ld_do, a.ld_dq, a.ld_dk, a.ld_dv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
-    check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd")
+    es = q.element_size()
+    _prof_launch("attn", "bf16" if q.dtype == torch.bfloat16 else "f32", 10.0 * B * nheads * S * S * 64, 8 * B * S * H * es,     # Q, K, V, O, dO in; dQ, dK, dV out
+                 lambda: check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd"))
     return dqkv
 
 
@@ -267,7 +294,8 @@ def ln_fwd(x, gamma, beta, eps, *, want_f32=True, lp_dtype=None, act=0):
     a.y_f32, a.y_lp, a.lp_dtype = ptr(y32), ptr(ylp), dt(lp_dtype) if lp_dtype is not None else 0
     a.mean, a.rstd = ptr(mean), ptr(rstd)
     a.rows, a.W, a.ld_x, a.ld_y, a.eps, a.act = rows, W, x.stride(0), W, eps, act
-    check(lib().tav_ln_fwd(C.byref(a), stream()), "ln_fwd")
+    nb = rows * W * (x.element_size() + (4 if want_f32 else 0) + (ylp.element_size() if ylp is not None else 0)) + rows * 8
+    _prof_launch("ln", "hbm", 0.0, nb, lambda: check(lib().tav_ln_fwd(C.byref(a), stream()), "ln_fwd"))
     return y32, ylp, mean, rstd
 
 
@@ -288,7 +316,9 @@ def ln_bwd(dy, x, gamma, beta, mean, rstd, *, dx_add=None, want_f32=True, lp_dty
     a.dx_f32, a.dx_lp, a.lp_dtype = ptr(dx32), ptr(dxlp), dt(lp_dtype) if lp_dtype is not None else 0
     a.dgamma, a.dbeta, a.partials, a.accumulate_params = ptr(dgamma), ptr(dbeta), ptr(part), 0
     a.rows, a.W, a.ld_x, a.ld_dy, a.ld_dx, a.act = rows, W, x.stride(0), dy.stride(0), W, act
-    check(lib().tav_ln_bwd(C.byref(a), stream()), "ln_bwd")
+    nb = rows * W * (x.element_size() + dy.element_size() + (4 if dx_add is not None else 0) + (4 if want_f32 else 0)
+                     + (dxlp.element_size() if dxlp is not None else 0)) + rows * 8
+    _prof_launch("ln", "hbm", 0.0, nb, lambda: check(lib().tav_ln_bwd(C.byref(a), stream()), "ln_bwd"))
     return dx32, dxlp, dgamma, dbeta
 
 

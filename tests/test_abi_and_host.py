@@ -451,3 +451,36 @@ def test_specaugment_distribution_matches_hf_compute_mask_indices():
     ours, hf = ours / trials, hf / trials
     assert torch.allclose(ours, hf, rtol=0.08), (ours, hf)
     assert (pre._mask_hidden_states(torch.zeros(B * T, Ha), B, T, amask, training=False) == 0).all()      # train=False: untouched
+
+
+def test_emitted_isa_discipline():
+    """tools/check_isa.py on the built library: every M0 write belongs to one of common.h's LDS-DMA sequences and nothing
+    else touches M0 (the GEMM loops do not save it); every v_readfirstlane_b32 keeps its wait states (to_sgpr's hand-placed s_nops).  Plus
+    the checker itself on hand-written disassembly with each violation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    ci = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ci)
+    if not os.path.exists(ci.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    problems, stats = ci.check(os.path.join(ROOT, "multi-modal-emotion_amd", "libtavhip.so"))
+    assert stats["lds_dma"] > 1000 and stats["readfirstlane"] > 100 and stats["m0_writes"] >= stats["lds_dma"]
+    assert not problems, problems[:5]
+    good = """
+0000000000001000 <k>:
+\ts_mov_b32 m0, s5
+\ts_nop 0
+\tglobal_load_lds_dwordx4 v1, s[2:3]
+\tv_mov_b32_e32 v7, v3
+\ts_nop 1
+\tv_readfirstlane_b32 s9, v7
+\ts_nop 4
+\tglobal_load_dword v2, v1, s[8:9]
+"""
+    assert ci.check_text([("good", good)])[0] == []
+    bad_m0 = good.replace("\ts_nop 0\n\tglobal_load_lds", "\tglobal_load_lds")                       # no wait state between the M0 write and the DMA
+    bad_user = good + "\ts_movrels_b32 s1, s2\n"                                                     # a compiler-made M0 user
+    bad_lane = good.replace("\ts_nop 1\n\tv_readfirstlane", "\tv_readfirstlane")                     # VALU write -> lane read, no wait state
+    bad_vmem = good.replace("\ts_nop 4\n", "\ts_nop 1\n")                                            # VMEM reads the SGPR 2 wait states later
+    for txt in (bad_m0, bad_user, bad_lane, bad_vmem):
+        assert ci.check_text([("bad", txt)])[0], txt

@@ -27,8 +27,11 @@ def family(name):
     return m.group(1) if m else None
 
 
-def read(dirname, counter):
-    tot, cnt = {}, {}
+def read(dirname, counter, steps_in_trace=1, skip_steps=0):
+    """Sum of `counter` and number of launches per kernel family.  The trace holds `steps_in_trace` identical steps (same kernels, same order);
+    the first `skip_steps` of them -- the EAGER warm-up before the hipGraph capture -- are dropped per family (by dispatch order), so the
+    averages are over replayed steps only."""
+    rows = {}
     files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         sys.exit(f"no *counter_collection.csv under {dirname}")
@@ -40,8 +43,14 @@ def read(dirname, counter):
                 fam = family(row["Kernel_Name"])
                 if fam is None:
                     continue
-                tot[fam] = tot.get(fam, 0.0) + float(row["Counter_Value"])
-                cnt[fam] = cnt.get(fam, 0) + 1
+                rows.setdefault(fam, []).append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
+    tot, cnt = {}, {}
+    for fam, rs in rows.items():
+        rs.sort()
+        drop = len(rs) * skip_steps // steps_in_trace if (steps_in_trace > 0 and len(rs) % steps_in_trace == 0) else 0
+        keep = rs[drop:]
+        tot[fam] = sum(v for _, v in keep)
+        cnt[fam] = len(keep)
     return tot, cnt
 
 
@@ -61,9 +70,11 @@ def main():
     ap.add_argument("--batch", type=int, required=True)
     ap.add_argument("--preset", default="B")
     ap.add_argument("--head", default="")
+    ap.add_argument("--steps-in-trace", type=int, default=5, help="steps the profiled command executed (warm-up + 2 post-capture replays + timed steps)")
+    ap.add_argument("--skip-steps", type=int, default=1, help="leading EAGER steps to drop (the warm-up before the capture)")
     a = ap.parse_args()
-    ft, fc = read(a.fetch_dir, "FETCH_SIZE")
-    wt, wc = read(a.write_dir, "WRITE_SIZE")
+    ft, fc = read(a.fetch_dir, "FETCH_SIZE", a.steps_in_trace, a.skip_steps)
+    wt, wc = read(a.write_dir, "WRITE_SIZE", a.steps_in_trace, a.skip_steps)
     fams = {}
     for k in sorted(ft):
         if k not in wt:
@@ -78,8 +89,8 @@ def main():
         except Exception:
             head = ""
     rec = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) over `python3 bench.py --steps 2 --warmup 1 "
-                   "--no-cpu-baseline --no-roofline --no-secondary` (hipGraph replay + the eager warm-up/capture steps); KiB per launch averaged over every "
-                   "launch of the kernel family; corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 counts 64 B per 128-B read request, MI355X_MICROARCH.md)",
+                   "--no-cpu-baseline --no-roofline --no-secondary`; the eager warm-up step is dropped (first 1/5 of every family's dispatches): KiB per launch "
+                   "averaged over the REPLAYED steps only; raw per-dispatch CSVs beside this file (*.csv.gz); corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 counts 64 B per 128-B read request, MI355X_MICROARCH.md)",
            "kernel_source_hash": source_hash(), "head": head, "preset": a.preset, "per_gpu_batch": a.batch, "families": fams}
     with open(a.out, "w") as f:
         json.dump(rec, f, indent=1)
