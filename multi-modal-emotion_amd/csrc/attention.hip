@@ -32,6 +32,9 @@
 #ifndef TAV_DKDV_BQ
 #define TAV_DKDV_BQ 64       // bf16 query-tile height of the dK/dV kernel (32 or 64)
 #endif
+#ifndef TAV_DKDV_FAST32
+#define TAV_DKDV_FAST32 1    // the unmasked pre-scaled bf16 dK/dV kernel (video / audio stacks) on 32-query tiles at THREE waves per SIMD (168 VGPRs, no scratch)
+#endif
 
 namespace tav {
 
@@ -158,42 +161,47 @@ TAV_DEV void row_frags_gload(uint4* f, const char* base, long ld_bytes, int r, i
 // rows [16w, 16w + 16) of both images.  The lane offsets are constants of the kernel and the tile walks on the SCALAR bases: a regular
 // tile costs no vector instruction for its addresses.  RAGGED (the last tile when S % 64 != 0): rows past S-1 step back to row S-1 --
 // finite data; the consumer gives those rows / keys weight zero (-inf logits).
-struct PairDma {
+template <int ROWS = 64> struct PairDmaT {
+    static constexpr int NP = ROWS / 32;       // 1-KiB pieces (8 rows) per wave and operand
     const char* a; const char* b;
     unsigned lda_b, ldb_b;             // bytes per row
-    unsigned offa[2], offb[2];
-    unsigned lds_a, lds_b;             // LDS byte addresses of this wave's 16 rows in slot 0 (wave-uniform)
+    unsigned offa[NP], offb[NP];
+    unsigned lds_a, lds_b;             // LDS byte addresses of this wave's rows in slot 0 (wave-uniform)
     int S, wave;
     TAV_DEV void init(const char* a_, const char* b_, long lda_bytes, long ldb_bytes, int S_, const void* lds_img_a, const void* lds_img_b, int tid) {
         a = a_; b = b_; lda_b = (unsigned)lda_bytes; ldb_b = (unsigned)ldb_bytes; S = S_;
         const int lane = tid & 63;
         wave = tid >> 6;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        for (int j = 0; j < NP; ++j) {
+            const int row = wave * 8 * NP + j * 8 + (lane >> 3), slot = lane & 7;
             const int ch = slot ^ (((row >> 1) & 3) << 1);
             offa[j] = (unsigned)row * lda_b + (unsigned)(ch * 16);      // (32-bit: the host checks that a slice fits)
             offb[j] = (unsigned)row * ldb_b + (unsigned)(ch * 16);
         }
-        lds_a = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_a) + wave * 16 * 128);
-        lds_b = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_b) + wave * 16 * 128);
+        lds_a = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_a) + wave * 8 * NP * 128);
+        lds_b = __builtin_amdgcn_readfirstlane(lds_addr(lds_img_b) + wave * 8 * NP * 128);
     }
     template <bool RAGGED> TAV_DEV void issue(int t, unsigned slot_bytes) const {
-        const char* ab = a + (size_t)t * 64u * lda_b;
-        const char* bb = b + (size_t)t * 64u * ldb_b;
-        unsigned oa[2] = {offa[0], offa[1]}, ob[2] = {offb[0], offb[1]};
+        const char* ab = a + (size_t)t * (unsigned)ROWS * lda_b;
+        const char* bb = b + (size_t)t * (unsigned)ROWS * ldb_b;
+        unsigned oa[NP], ob[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { oa[j] = offa[j]; ob[j] = offb[j]; }
         if constexpr (RAGGED) {
             int ln = threadIdx.x & 63;
             asm volatile("" : "+v"(ln));                 // (re-materialised here: nothing of this is hoisted above the loop and kept live)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int over = t * 64 + wave * 16 + j * 8 + (ln >> 3) - (S - 1);
+            for (int j = 0; j < NP; ++j) {
+                const int over = t * ROWS + wave * 8 * NP + j * 8 + (ln >> 3) - (S - 1);
                 if (over > 0) { oa[j] -= (unsigned)over * lda_b; ob[j] -= (unsigned)over * ldb_b; }
             }
         }
-        glds16_x4(ab, bb, oa[0], oa[1], ob[0], ob[1], lds_a + slot_bytes, lds_b + slot_bytes);
+        if constexpr (NP == 2) glds16_x4(ab, bb, oa[0], oa[1], ob[0], ob[1], lds_a + slot_bytes, lds_b + slot_bytes);
+        else glds16_x2(ab, bb, oa[0], ob[0], lds_a + slot_bytes, lds_b + slot_bytes);
     }
 };
+using PairDma = PairDmaT<64>;
 
 // ================================================================================================= forward
 // ablation switches for the forward kernel (tools/ab_build.sh; timing experiments only, results are wrong with any of them set)
@@ -557,7 +565,8 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
 // ================================================================================================= backward: dK, dV
 // query-tile height of the dK/dV kernel: 64 for bf16 (half as many barriers and staging round trips per MFMA as 32), 32 for
 // f32 (register budget)
-template <typename T> constexpr int dkdv_bq() { return sizeof(T) == 2 ? TAV_DKDV_BQ : 32; }
+template <typename T, int MODE, bool PRE> constexpr bool dkdv_fast32() { return TAV_DKDV_FAST32 && sizeof(T) == 2 && MODE == 0 && PRE; }
+template <typename T, int MODE, bool PRE> constexpr int dkdv_bq() { return sizeof(T) == 2 ? (dkdv_fast32<T, MODE, PRE>() ? 32 : TAV_DKDV_BQ) : 32; }
 
 // (waves per SIMD the backward kernels are compiled for: at 3 both spill -- 48..256 B of scratch -- which halved the forward's speed when tried there)
 #ifndef TAV_ATT_DKDV_OCC
@@ -567,11 +576,11 @@ template <typename T> constexpr int dkdv_bq() { return sizeof(T) == 2 ? TAV_DKDV
 #define TAV_ATT_DQ_OCC 2
 #endif
 template <typename T, int MODE, bool PRE>
-__global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (dkdv_fast32<T, MODE, PRE>() ? 3 : TAV_ATT_DKDV_OCC)) void attn_bwd_dkdv_kernel(const AttnP p) {
     using H = HD<T>;
-    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T>(), NQT = BQ / 16;
+    constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BQ = dkdv_bq<T, MODE, PRE>(), NQT = BQ / 16;
     constexpr int NCH = BQ * H::ROWCH / 256;
-    constexpr bool DMA = (ES == 2) && TAV_ATT_DMA && BQ == 64;   // bf16: Q / dO tiles by LDS-DMA (PairDma: 64-row tiles); f32: register staging
+    constexpr bool DMA = (ES == 2) && TAV_ATT_DMA;              // bf16: Q / dO tiles by LDS-DMA (PairDmaT<BQ>); f32: register staging
     constexpr int ROW_B = BQ * H::ROWB, NAT_B = H::DUAL ? 0 : BQ * H::PITCH_N;
     constexpr int BUF_B = 2 * ROW_B + 2 * NAT_B + 2 * BQ * 4;   // Qrow, dOrow, [Qnat, dOnat: f32 only], lse, delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
         tile_addr_init<T, BQ>(do_off0, do_max, p.ld_do * ES, S, tid);
     }
     const unsigned qstep_b = (unsigned)(BQ * p.ld_q * ES), dostep_b = (unsigned)(BQ * p.ld_do * ES);
-    PairDma qd;
+    PairDmaT<(ES == 2 ? BQ : 64)> qd;
     if constexpr (DMA) qd.init(Qb, dOb, p.ld_q * ES, p.ld_do * ES, S, smem, smem + ROW_B, tid);
     // lane constants of the fragment reads (bf16 row images; see attn_fwd_kernel): the row reads of Q and dO share one per k-step, the
     // transposed reads one per d-tile
@@ -727,9 +736,14 @@ __global__ __launch_bounds__(256, TAV_ATT_DKDV_OCC) void attn_bwd_dkdv_kernel(co
             // kadd is zero except under a pre-softmax mask (MODE 1) and for keys past S (-inf): wave-uniform choice.
             if (with_kadd) {
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt) {
+                    // (without a pre-softmax mask the term is 0 / -inf past S: re-derived here, on the ragged key block only, instead of
+                    // living in two registers across the whole loop -- the 32-query form of this kernel sits at the 168-register line)
+                    float ka = kadd[kt];
+                    if constexpr (MODE != 1) { int ky = k0 + 16 * kt + i; asm volatile("" : "+v"(ky)); ka = ky < S ? 0.f : -INFINITY; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(PRE ? sacc[qt][kt][r] + kadd[kt] : __builtin_fmaf(sacc[qt][kt][r], c2, kadd[kt]));
+                    for (int r = 0; r < 4; ++r) sacc[qt][kt][r] = fast_exp2(PRE ? sacc[qt][kt][r] + ka : __builtin_fmaf(sacc[qt][kt][r], c2, ka));
+                }
             } else {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -1027,8 +1041,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
 template <typename T> constexpr size_t fwd_lds() {
     return 2 * (64 * HD<T>::ROWB + 64 * HD<T>::PITCH_N + 2 * 64 * 4) + (256 + 64) * 4;
 }
-template <typename T> constexpr size_t dkdv_lds() {
-    return 2 * (2 * dkdv_bq<T>() * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * dkdv_bq<T>() * HD<T>::PITCH_N) + 2 * dkdv_bq<T>() * 4) + (256 + 64) * 4;
+template <typename T, int MODE, bool PRE> constexpr size_t dkdv_lds() {
+    constexpr int BQ = dkdv_bq<T, MODE, PRE>();
+    return 2 * (2 * BQ * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 2 * BQ * HD<T>::PITCH_N) + 2 * BQ * 4) + (256 + 64) * 4;
 }
 template <typename T> constexpr size_t dq_lds() { return 2 * (2 * 64 * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 64 * HD<T>::PITCH_N) + 64 * 4); }
 
@@ -1076,7 +1091,8 @@ template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, 
 template <typename T, int MODE, bool PRE> static int launch_bwd(const AttnP& p, hipStream_t st) {
     dim3 grid((p.S + 127) / 128, p.nh, p.B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, p);        // also writes delta [B][nh][S]
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), dkdv_lds<T>(), st, p);    // reads it
+    constexpr size_t lds_dkdv = dkdv_lds<T, MODE, PRE>();
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), lds_dkdv, st, p);    // reads it
     return (int)hipGetLastError();
 }
 template <typename T, bool PRE> static int dispatch_fwd(const AttnP& p, int mode, hipStream_t st) {

@@ -189,6 +189,16 @@ TAV_DEV void glds16_x4(const void* abase, const void* bbase, unsigned va0, unsig
                  : "v"(va0), "v"(va1), "v"(vb0), "v"(vb1), "s"(abase), "s"(bbase), "s"(lds_a), "s"(lds_b)
                  : "memory", "scc");
 }
+TAV_DEV void glds16_x2(const void* abase, const void* bbase, unsigned va0, unsigned vb0, unsigned lds_a, unsigned lds_b) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(va0), "v"(vb0), "s"(abase), "s"(bbase), "s"(lds_a), "s"(lds_b)
+                 : "memory");
+}
 // Values loaded from global memory BEFORE a loop and consumed inside it: hipcc's waitcnt pass cannot tell how many younger loads
 // a conditional in-loop prefetch has put in flight, so it protects every in-loop use with `s_waitcnt vmcnt(0/1)` -- which drains
 // the prefetch issued a few instructions earlier and exposes the full memory latency on every tile.  settle() makes the register
