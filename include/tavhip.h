@@ -349,6 +349,19 @@ int tav_adamw_chunked(float* const* params, const float* const* grads, float* co
                       const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks, const float* clip_coef, const float* lr, float beta1,
                       float beta2, float eps, float weight_decay, int32_t* step, float* bias_corr, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Data-parallel exchange: the ONE collective of the path, the mean of a gradient bucket over the ranks of a node
+ * (RCCL over xGMI), for hosts that do not come with a collective library of their own.  One process per GPU; every rank calls
+ * tav_allreduce_bucket for the same buckets in the same order.  `comm` is an RCCL communicator created with tav_comm_init_rank (rank 0
+ * makes the 128-byte id with tav_comm_unique_id and ships it to the others by its own means).  The all-reduce is enqueued on `stream`
+ * (in place, mean, f32 or bf16 elements); returns 1000 + ncclResult_t when RCCL refuses.  The reference has no distributed code; this
+ * replaces what torch DistributedDataParallel would do around train_model/tav_train.py:59-62.  The Python host layer (ddp.py) issues the
+ * same collective through torch.distributed's "nccl" backend, which IS RCCL on ROCm. */
+int tav_comm_unique_id(void* out128);
+int tav_comm_init_rank(void** comm, int32_t nranks, const void* unique_id128, int32_t rank);
+int tav_comm_destroy(void* comm);
+int tav_allreduce_bucket(void* buf, int64_t nbytes, int32_t dtype, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,10 @@ _SIGS = {
     "tav_fp8_amax": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp]),
     "tav_fp8_quantize": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, i64, vp]),
     "tav_splitk_reduce": (C.c_int, [vp, vp, i32, i64, i32, vp]),
+    "tav_comm_unique_id": (C.c_int, [vp]),
+    "tav_comm_init_rank": (C.c_int, [C.POINTER(vp), i32, vp, i32]),
+    "tav_comm_destroy": (C.c_int, [vp]),
+    "tav_allreduce_bucket": (C.c_int, [vp, i64, i32, vp, vp]),
     "tav_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_ln_fwd": (C.c_int, [C.POINTER(LnArgs), vp]),

@@ -806,3 +806,26 @@ def test_config5_parity_vs_oracle(gpu, policy, tol):
     print(f"[config 5, {policy}] logits {e[0]:.2e} loss {e[1]:.2e} grad-norm {e[2]:.2e} worst tensor {worst:.2e} ({worst_k})")
     assert max(e) < tol, e
     assert worst < {"fp32": 1e-3, "bf16": 3e-2, "fp8": 0.15, "fp8-all": 0.3}[policy], (worst, worst_k)
+
+
+def test_c_abi_allreduce_bucket_single_rank(gpu):
+    """the C ABI's own gradient-bucket collective (RCCL, tav_allreduce_bucket) with one rank: communicator from a unique id,
+    in-place mean enqueued on the caller's stream (f32 and bf16), communicator destroyed."""
+    import ctypes
+    from tav_amd import _lib
+    from tav_amd._lib import ptr, stream
+    h = _lib.lib()
+    uid = ctypes.create_string_buffer(128)
+    assert h.tav_comm_unique_id(uid) == 0
+    comm = ctypes.c_void_p()
+    assert h.tav_comm_init_rank(ctypes.byref(comm), 1, uid, 0) == 0 and comm.value
+    try:
+        for dtype, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            x = torch.randn(1 << 20, device="cuda").to(dtype)
+            ref = x.clone()
+            assert h.tav_allreduce_bucket(ptr(x), x.numel() * x.element_size(), code, comm, stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(x, ref)                      # the mean over one rank
+        assert h.tav_allreduce_bucket(None, 4, 0, comm, stream()) == -1 and h.tav_allreduce_bucket(ptr(x), 3, 0, comm, stream()) == -2
+    finally:
+        assert h.tav_comm_destroy(comm) == 0
