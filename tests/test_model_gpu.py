@@ -368,8 +368,10 @@ def test_rccl_reducer_single_rank(gpu, monkeypatch):
                     assert torch.equal(g0[k], g1[k]), k
         else:                                 # after one update (embedding-table rounding differs in the last bit): equal to rounding
             assert abs(l0 - l1) / abs(l0) < 1e-4
-            for k in g0:
-                assert rel(g0[k], g1[k]) < 2e-2, k
+            gmax = max(v.abs().max().item() for v in g0.values())
+            for k in g0:                      # (floor: a key bias has a zero true gradient -- the softmax is invariant to it -- and holds rounding noise only)
+                e = (g0[k].double() - g1[k].double()).abs().max().item() / (g0[k].abs().max().item() + 1e-3 * gmax)
+                assert e < 2e-2, (k, e)
 
 
 def test_best_pt_resume_continues(gpu, tmp_path):
