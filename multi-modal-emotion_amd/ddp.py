@@ -283,7 +283,8 @@ class SegmentedBackward:
         return self.final[s]
 
 
-_SKIP_REDUCE = os.environ.get("TAV_DDP_SKIP_REDUCE", "0") == "1"     # measurement knob: time the graph chain without the collective (results unreduced)
+_SKIP_REDUCE = os.environ.get("TAV_DDP_SKIP_REDUCE", "0") == "1"
+ARENA = os.environ.get("TAV_DDP_ARENA", "1") == "1"      # gradient arena: the layers' weight-gradient kernels write into the bucket (0: pack everything by copy)     # measurement knob: time the graph chain without the collective (results unreduced)
 
 
 class GraphedStep:
@@ -304,7 +305,7 @@ class GraphedStep:
         if fractions is None:
             fractions = tuple(runtime.CUT_FRACTIONS) if k == 4 else tuple((j + 0.25) / k for j in range(k - 1)) if k > 1 else ()
         self.fractions = tuple(fractions)
-        self.graphs, self.flats = [], []
+        self.graphs, self.flats, self.groups = [], [], []
         self._plan = None                           # [(parameter names / sizes per bucket)] fixed by the first pass, checked on later eager ones
         if not self.use_graphs:
             self.loss = None
@@ -314,9 +315,11 @@ class GraphedStep:
         mode = dict(capture_error_mode="thread_local")
         g0 = torch.cuda.CUDAGraph()
         runtime.begin_cuts(self.fractions)
+        runtime.begin_layer_groups()
         with torch.cuda.graph(g0, stream=stream, **mode):
             self.loss = forward_loss()
             self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
+            self.groups = runtime.end_layer_groups()
             self._run_and_pack(0)
         self.graphs.append(g0)
         for s in range(1, self.seg.nseg):
@@ -335,29 +338,89 @@ class GraphedStep:
         red._bucket_of = {p: i for i, (plist, _) in enumerate(red.buckets) for p in plist}
         red._pending, red._streams, red._works = {}, {}, []
 
+    def _bucket_order(self, params):
+        """Order of a segment's parameters inside its bucket: as the autograd walk found them, except that the members of one transformer
+        layer (runtime.note_layer_group) stand together in the order wq wk wv | bq bk bv | wo bo w1 b1 w2 b2 -- the grouped weight-gradient
+        launch writes Wq | Wk | Wv as ONE fused tensor, so their slots must be adjacent.  Deterministic, hence identical on every rank."""
+        member = {}
+        for gi, grp in enumerate(self.groups):
+            for p in grp:
+                if p is not None:
+                    member[id(p)] = gi
+        have = {id(p) for p in params}
+        out, done = [], set()
+        for p in params:
+            gi = member.get(id(p))
+            if gi is None or not all(q is None or id(q) in have for q in self.groups[gi]):
+                if id(p) not in done:
+                    out.append(p)
+                    done.add(id(p))
+                continue
+            if gi in done:
+                continue
+            done.add(gi)
+            for q in self.groups[gi]:
+                if q is not None and id(q) not in done:
+                    out.append(q)
+                    done.add(id(q))
+        return out
+
     def _run_and_pack(self, s):
-        plist = [p for p in self.seg.run(s) if p.grad is not None]
+        from . import runtime
+        expected = self._bucket_order([p for p in self.seg.final[s] if p.requires_grad])
+        flat, views = None, {}
+        if expected and ARENA:
+            n = sum(p.numel() for p in expected)
+            reuse = self.flats[s][1] if len(self.flats) > s and self.flats[s][1] is not None else None     # (eager mode: keep the buffers)
+            # allocated inside the capture, i.e. from the graphs' private pool: the reference kept in self.flats pins it for good, and
+            # the reducer / RCCL streams only ever touch it between two replays.  (+ the reducer's per-parameter "used" flags, all ones:
+            # in this mode every bucketed parameter must produce a gradient every step)
+            if reuse is not None and reuse.numel() == n + len(expected):
+                flat = reuse
+            else:
+                flat = torch.empty(n + len(expected), dtype=torch.float32, device=expected[0].device)
+                flat[n:].fill_(1.0)
+            off = 0
+            for p in expected:
+                views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            # the gradient ARENA: the layers' grouped weight-gradient launches of this segment write straight into these views
+            runtime.grad_slots.clear()
+            runtime.grad_slots.update({p.data_ptr(): views[id(p)] for p in expected})
+        try:
+            plist = [p for p in self.seg.run(s) if p.grad is not None]
+        finally:
+            runtime.grad_slots.clear()
         if not plist:                                # a segment that finalises no parameter (shallow stack, few cuts): nothing to ship
-            self.flats.append(([], None))
+            if len(self.flats) > s:
+                self.flats[s] = ([], None)
+            else:
+                self.flats.append(([], None))
             return
-        n = sum(p.numel() for p in plist)
-        reuse = self.flats[s][1] if len(self.flats) > s and self.flats[s][1] is not None else None     # (eager mode: keep the buffers)
-        # allocated inside the capture, i.e. from the graphs' private pool: the reference kept in self.flats pins it for good, and
-        # the reducer / RCCL streams only ever touch it between two replays.  (+ the reducer's per-parameter "used" flags, all ones:
-        # in this mode every bucketed parameter must produce a gradient every step)
-        if reuse is not None and reuse.numel() == n + len(plist):
-            flat = reuse
+        if flat is not None and {id(p) for p in plist} == {id(p) for p in expected}:
+            plist = expected                         # (bucket order = the planned one)
         else:
+            # (no arena, or a parameter of the plan produced no gradient: lay the bucket out from what is there)
+            plist = self._bucket_order(plist)
+            n = sum(p.numel() for p in plist)
             flat = torch.empty(n + len(plist), dtype=torch.float32, device=plist[0].device)
             flat[n:].fill_(1.0)
-        views, off = [], 0
+            views, off = {}, 0
+            for p in plist:
+                views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        src, dst = [], []
         for p in plist:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        with torch.no_grad():
-            torch._foreach_copy_(views, [p.grad for p in plist])
-        for p, v in zip(plist, views):
-            p.grad = v
+            v = views[id(p)]
+            if p.grad.data_ptr() != v.data_ptr():    # not written in place by its kernel: pack it
+                src.append(p.grad)
+                dst.append(v)
+        self.in_place = getattr(self, "in_place", 0) + sum(p.numel() for p in plist) - sum(t.numel() for t in src)
+        if dst:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+        for p in plist:
+            p.grad = views[id(p)]
         if len(self.flats) > s:
             self.flats[s] = (plist, flat)
         else:
@@ -400,8 +463,10 @@ class GraphedStep:
         for p in self.red.params:
             p.grad = None
         runtime.begin_cuts(self.fractions)
+        runtime.begin_layer_groups()
         self.loss = self._forward_loss()
         self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
+        self.groups = runtime.end_layer_groups()
         for s in range(self.seg.nseg):
             self._run_and_pack(s)
             flat = self.flats[s][1]
@@ -425,5 +490,7 @@ class GraphedStep:
     def describe(self):
         sizes = ", ".join(f"{(flat.numel() * 4 / 2 ** 20) if flat is not None else 0:.0f}" for _, flat in self.flats)
         how = f"{len(self.graphs)} hipGraphs" if self.use_graphs else "eager chain"
+        tot = sum(flat.numel() - len(pl) for pl, flat in self.flats if flat is not None)
+        arena = f"; gradient arena: {100.0 * getattr(self, 'in_place', 0) / max(tot, 1):.0f} % of the bucket elements written in place by their kernels" if ARENA else ""
         return (f"{how} (forward + backward cut into {self.seg.nseg} segments) + optimizer {'graph' if self.use_graphs else 'call'}; bucket s all-reduced "
-                f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; buckets [{sizes}] MiB")
+                f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; buckets [{sizes}] MiB{arena}")

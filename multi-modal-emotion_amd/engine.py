@@ -237,13 +237,24 @@ GROUPED_WGRAD = [os.environ.get("TAV_GROUPED_WGRAD", "1") == "1"]
 QSC = ops.ATTN_Q_PRESCALE if os.environ.get("TAV_ATTN_PRESCALE", "1") == "1" else None
 
 
-def _layer_wgrads(pairs):
+def _layer_wgrads(pairs, into=None):
     """Weight and bias gradients of one layer's linears, [(dY_lp, X_lp), ...] -> [(dW, db), ...].  One grouped launch in which
-    every tile sums over all tokens (no split slabs, no reduce kernels) when the layer's tiles fill the chip; else one TN GEMM each."""
+    every tile sums over all tokens (no split slabs, no reduce kernels) when the layer's tiles fill the chip; else one TN GEMM each.
+    into: destinations inside a data-parallel bucket (see _arena_into), honoured by the grouped launch."""
     tiles = sum(((a.shape[1] + 127) // 128) * ((b.shape[1] + 127) // 128) for a, b in pairs)
     if GROUPED_WGRAD[0] and len(pairs) <= 4 and tiles >= 256:
-        return ops.gemm_tn_grouped(pairs, want_bias=True)
+        return ops.gemm_tn_grouped(pairs, want_bias=True, into=into)
     return [ops.gemm_tn(a, b, want_bias=True) for a, b in pairs]
+
+
+def _arena_into(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2):
+    """Gradient-arena destinations of one layer's grouped weight-gradient launch, in its pair order (W2, W1, Wo, Wqkv), or None when no
+    data-parallel capture has registered slots (runtime.grad_slots).  Wq | Wk | Wv need adjacent slots: their gradient is one fused tensor."""
+    from . import runtime as _rt
+    if not _rt.grad_slots:
+        return None
+    g = lambda p: _rt.grad_slots.get(p.data_ptr()) if p is not None else None       # noqa: E731
+    return [(g(w2), g(b2)), (g(w1), g(b1)), (g(wo), g(bo)), (_rt.fused_slot((wq, wk, wv)), _rt.fused_slot((bq, bk, bv)) if (bq is not None and bk is not None and bv is not None) else None)]
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -262,6 +273,8 @@ class EncoderLayerFn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
+        from . import runtime as _rt
+        _rt.note_layer_group(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2)          # (data-parallel gradient arena: which gradients one grouped launch produces)
         # the q third of qkv comes out of the projection already multiplied by scale * log2(e) (folded into the weight copy)
         wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
         x = _c(x)
@@ -337,7 +350,8 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             g0 = ops.gemm_nt(dqkv, wqkv_t, resid=dy1, out_dtype=torch.float32)
         # the four weight (+bias) gradients of the layer: leaves nobody reads before the optimizer, issued last as ONE grouped launch
-        (dW2, dB2), (dW1, dB1), (dWo, dBo), (dWqkv, dBqkv) = _layer_wgrads([(dy2_lp, h), (du, c), (dy1_lp, o), (dqkv, a)])
+        (dW2, dB2), (dW1, dB1), (dWo, dBo), (dWqkv, dBqkv) = _layer_wgrads([(dy2_lp, h), (du, c), (dy1_lp, o), (dqkv, a)],
+                                                                           _arena_into(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2))
         grads = [dg1, db1, dWqkv[:H], dBqkv[:H], dWqkv[H:2 * H], dBqkv[H:2 * H], dWqkv[2 * H:], dBqkv[2 * H:], dWo, dBo, dg2, db2, dW1, dB1, dW2, dB2]
         grads = [g if has else None for g, has in zip(grads, ctx.has)]
         return (g0, None, None, None, None, *grads)

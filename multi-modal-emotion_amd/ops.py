@@ -144,10 +144,12 @@ def gemm_tn(a, b, *, out=None, accumulate=False, N1=None, N2=None, lda=None, ldb
     return (out, dbias) if want_bias else out
 
 
-def gemm_tn_grouped(pairs, want_bias=True, flags=0):
+def gemm_tn_grouped(pairs, want_bias=True, flags=0, into=None):
     """[(A_k [rows, N1_k], B_k [rows, N2_k]), ...] (<= 4, same rows and dtype) -> [(dW_k [N1_k, N2_k] f32, db_k [N1_k] f32 | None), ...]
     in ONE launch (the weight gradients of one transformer layer): 128-wide tiles that each sum over all rows, or -- bf16, large problems --
-    256-wide tiles with the rows split over workgroups into f32 slabs plus a fixed-order reduce (the library decides; `flags` as in tavhip.h)."""
+    256-wide tiles with the rows split over workgroups into f32 slabs plus a fixed-order reduce (the library decides; `flags` as in tavhip.h).
+    into: optional [(dW_buffer | None, db_buffer | None), ...] -- contiguous f32 destinations (the data-parallel gradient arena: the kernels
+    write the bucket directly, ddp.GraphedStep); missing entries are allocated."""
     n = len(pairs)
     rows, dtype = pairs[0][0].shape[0], pairs[0][0].dtype
     probs = (L.GemmTNProblem * n)()
@@ -155,8 +157,10 @@ def gemm_tn_grouped(pairs, want_bias=True, flags=0):
     for k, (a, b) in enumerate(pairs):
         assert a.shape[0] == rows and b.shape[0] == rows and a.dtype == dtype and b.dtype == dtype
         N1, N2 = a.shape[1], b.shape[1]
-        dW = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
-        db = torch.empty(N1, dtype=torch.float32, device=a.device) if want_bias else None
+        dW_to, db_to = into[k] if into is not None else (None, None)
+        dW = dW_to if dW_to is not None else torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+        db = (db_to if db_to is not None else torch.empty(N1, dtype=torch.float32, device=a.device)) if want_bias else None
+        assert dW.shape == (N1, N2) and dW.is_contiguous() and dW.dtype == torch.float32 and (db is None or (db.shape == (N1,) and db.is_contiguous()))
         pr = probs[k]
         pr.A, pr.B, pr.out, pr.dbias = ptr(a), ptr(b), ptr(dW), ptr(db)
         pr.N1, pr.N2, pr.lda, pr.ldb = N1, N2, a.stride(0), b.stride(0)

@@ -113,3 +113,42 @@ def cut_point(branch, i, L, x):
     xc = x.detach().requires_grad_(True)
     _cut_rec["pts"].setdefault(branch, []).append((x, xc))
     return xc
+
+
+# ---- gradient arena (ddp.GraphedStep): while a data-parallel step is being captured, the weight-gradient kernels of a transformer layer
+# write straight into the bucket that will be all-reduced, so that bucket needs no pack copy.  `grad_slots` maps parameter.data_ptr() -> its f32
+# view inside the bucket (the backward sees the parameters as unpacked saved tensors: other Python objects, same storage); `layer_groups` collects, during the forward, the parameter tuples whose gradients one grouped launch produces
+# (wq, wk, wv share ONE fused [3H, K] output, so their views must be adjacent and in that order).
+grad_slots = {}
+layer_groups = None
+
+
+def begin_layer_groups():
+    global layer_groups
+    layer_groups = []
+
+
+def end_layer_groups():
+    global layer_groups
+    g, layer_groups = layer_groups, None
+    return g or []
+
+
+def note_layer_group(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2):
+    if layer_groups is not None:
+        layer_groups.append((wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2))
+
+
+def fused_slot(params):
+    """The arena views of `params` as ONE contiguous tensor [sum of rows, ...] if every one has a slot and they are adjacent in this order."""
+    views = [grad_slots.get(p.data_ptr()) if p is not None else None for p in params]
+    if any(v is None for v in views):
+        return None
+    ptr = views[0].data_ptr()
+    for v in views:
+        if v.data_ptr() != ptr:
+            return None
+        ptr += v.numel() * 4
+    base = views[0]
+    rows = sum(v.shape[0] for v in views)
+    return base.as_strided((rows,) + tuple(base.shape[1:]), base.stride())
