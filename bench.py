@@ -218,6 +218,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libtavhip has no CPU path")
+    # TAV_BENCH_REHEARSE=1: rehearsal of the N > 1 path on a ONE-GPU box -- every rank on cuda:0, process group "gloo" (RCCL refuses two ranks per
+    # device; the step's collectives are eager calls between hipGraphs, so the backend is interchangeable).  Its numbers mean nothing.
+    rehearse = os.environ.get("TAV_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     alone_ddp = world == 1 and os.environ.get("TAV_DDP_SINGLE_RANK", "0") == "1"      # exercise the data-parallel step with one rank
@@ -226,7 +231,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
 
     weak = args.batch_per_gpu > 0
     if weak:
@@ -517,7 +525,7 @@ def main():
             "metric": f"utterances/sec {what}, TAV (BERT+Wav2Vec2+VideoMAE) b={gb}, 1/2/4/8 MI355X",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearse else ""),
             "config": {"workload": f"tav_nn.py TAV preset {args.preset} ({describe(cfg)}), global batch {gb} = {b} per GPU x {world}, text 128 tok, audio 80000 "
                                    f"samples, video {cfg['video']['frames']}x3x{cfg['video']['image']}x{cfg['video']['image']} ({n_true} fusion / "
                                    f"{(cfg['video']['image'] // 16) ** 2 * (cfg['video']['frames'] // 2) - n_true} encoder tokens), {fwd_gf:.1f} GFLOP forward per utterance",
