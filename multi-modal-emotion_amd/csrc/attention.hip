@@ -241,8 +241,13 @@ constexpr bool ATT_ABL_NOBAR = false;
 //     accumulators come out as s - m and p = exp2(acc): no fma per score;
 //   * O / l are rescaled only when the tile maximum passes the reference by TAV_ATT_LAZY_THR (rare after the first tile);
 //   * ring slot, LDS addresses and the DMA source walk are compile-time / scalar: the loop body is instantiated once per slot.
+#ifndef TAV_ATT_FWD_NQ
+#define TAV_ATT_FWD_NQ 2     // 16-query tiles per wave of the unmasked pre-scaled bf16 forward (3: K/V fragment reads, DMA and barriers amortised over 1.5x the MFMAs; two waves per SIMD)
+#endif
+template <typename T, int MODE, bool PRE> constexpr int fwd_nq() { return (sizeof(T) == 2 && MODE == 0 && PRE) ? TAV_ATT_FWD_NQ : 2; }
 template <typename T, int MODE, bool PRE>
-__global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, (fwd_nq<T, MODE, PRE>() > 2 ? 2 : TAV_ATT_FWD_OCC)) void attn_fwd_kernel(const AttnP p) {
+    constexpr int NQ = fwd_nq<T, MODE, PRE>();             // 16-query tiles per wave (2; 3 = 48 queries per wave, 192 per workgroup)
     using H = HD<T>;
     constexpr int ES = H::ES, NSD = H::NSD, KSTEP = ET<T>::KSTEP, BKV = 64;
     constexpr int NCH = BKV * H::ROWCH / 256;
@@ -258,16 +263,16 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
     const int head = blockIdx.y, b = blockIdx.z, S = p.S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
     const long hoff = (long)head * 64 * ES;
     const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
     const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
     const char* Vb = p.v + (long)b * S * p.ld_v * ES + hoff;
     const float* maskb = p.mask ? p.mask + (long)b * S : nullptr;
 
-    uint4 qf[2][NSD];
+    uint4 qf[NQ][NSD];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q0 + 16 * qt + i, S, g);
+    for (int qt = 0; qt < NQ; ++qt) row_frags_gload<T>(qf[qt], Qb, p.ld_q * ES, q0 + 16 * qt + i, S, g);
 
     // softmax runs in the exp2 domain: t = s*scale*log2(e) + mask*log2(e); p = exp2(t - m).  The row sums l come out of the MFMA
     // pipe (a ones-row operand times P^T) instead of 32 VALU adds + shuffles per tile: the kernel is VALU-issue bound.
@@ -289,12 +294,18 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
             asm volatile("" : "+v"(vtoff[dt]));
         }
     }
-    float m_run[2] = {-1e30f, -1e30f};                                          // reference exponent of O / l per query (lane i, both q tiles)
-    f32x4 mneg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // PRE fast path: -m_run on all four rows = the C operand of QK^T
-    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // every register = sum_key P[key][q] (rows of the ones operand)
-    f32x4 oacc[4][2];
+    float m_run[NQ];                                          // reference exponent of O / l per query (lane i, both q tiles)
+    f32x4 mneg[NQ];   // PRE fast path: -m_run on all four rows = the C operand of QK^T
+    f32x4 lacc[NQ];   // every register = sum_key P[key][q] (rows of the ones operand)
+    f32x4 oacc[4][NQ];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { oacc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; oacc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = 0; qt < NQ; ++qt) {
+        m_run[qt] = -1e30f;
+        mneg[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) oacc[a][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float corr_part = 0.f;
 
     const int nkt = (S + BKV - 1) / BKV;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
     if constexpr (DMA) { if (nkt == 1) dma(0, 0, TagYes{}); else dma(0, 0, TagNo{}); }
     gload(0); lstore(0, 0);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQ; ++qt)
 #pragma unroll
         for (int s = 0; s < NSD; ++s) settle(qf[qt][s]);
     if constexpr (DMA) wait_vmcnt0();
@@ -367,9 +378,9 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
         const float* kadd = reinterpret_cast<const float*>(Vnat + VNAT_B);
         const float* cm = kadd + BKV;
 
-        f32x4 sacc[4][2];
+        f32x4 sacc[4][NQ];
         // S^T = K q^T: the accumulators start at cinit (fast path: -m_ref on every row, so s - m_ref comes out of the MFMA chain; else zero)
-        auto qk = [&](const f32x4 (&cinit)[2]) __attribute__((always_inline)) {
+        auto qk = [&](const f32x4 (&cinit)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NSD; ++s)
 #pragma unroll
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                     if constexpr (ES == 2) a = *reinterpret_cast<const uint4*>(Krow + koff[s] + kt * 16 * H::ROWB);
                     else a = *reinterpret_cast<const uint4*>(Krow + H::row_off(16 * kt + i, 4 * s + g));
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < NQ; ++qt) {
                         if (s == 0) sacc[kt][qt] = cinit[qt];
                         ATT_FWD_MMA(a, qf[qt][s], sacc[kt][qt]);
                     }
@@ -389,10 +400,10 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
             // sacc = s - m_ref.  Tile maximum per query; rescale only when it passes the reference by more than THR (or on the first tile,
             // where the reference is still undefined: mneg = 0, so sacc are the raw logits).
             const bool first = (t == 0);
-            float mx[2];
+            float mx[NQ];
             bool grow = first;
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < NQ; ++qt) {
                 // v_maximum3_f32 (IEEE maximum: no canonicalising v_max in front of MFMA results, as fmaxf needs): 8 instructions for 16 values
                 float m0 = vmax3(sacc[0][qt][0], sacc[0][qt][1], sacc[0][qt][2]);
                 m0 = vmax3(m0, sacc[0][qt][3], sacc[1][qt][0]);
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
             }
             if (__any(grow)) {                                     // rare after the first tile: move the reference, THEN take the common path
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < NQ; ++qt) {
                     const float shift = first ? mx[qt] : fmaxf(mx[qt], 0.f);         // new reference = old + shift (never lowered after tile 0)
                     m_run[qt] = first ? shift : m_run[qt] + shift;
                     mneg[qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
@@ -422,32 +433,36 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                 }
             }
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < NQ; ++qt)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = ATT_FWD_EXP2(sacc[kt][qt][r]);
         } else {
-            const f32x4 zero2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 zero2[NQ];
+#pragma unroll
+            for (int qt = 0; qt < NQ; ++qt) zero2[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
             qk(zero2);
             // running max per query (= per lane i, both q tiles), then p = exp2(s*c2 + kadd - m).  The per-key additive term is zero
             // except under a pre-softmax mask (MODE 1) and on the ragged last tile (-inf past S): only those tiles pay for it;
             // the others take the max over the raw scores and fold scale and max into one fma per element.
-            float alpha[2];
+            float alpha[NQ];
             bool moved = false;
             if constexpr (KADD) {
-                float mx[2] = {-INFINITY, -INFINITY};
+                float mx[NQ];
+#pragma unroll
+                for (int qt = 0; qt < NQ; ++qt) mx[qt] = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 16 * kt + 4 * g);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < NQ; ++qt) {
                         sacc[kt][qt] = PRE ? sacc[kt][qt] + ka : sacc[kt][qt] * c2 + ka;
                         mx[qt] = fmaxf(fmaxf(mx[qt], sacc[kt][qt][0]), fmaxf(sacc[kt][qt][1], fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
                     }
                 }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < NQ; ++qt) {
                     const float m_new = fmaxf(m_run[qt], max_over_row_groups(mx[qt]));
                     alpha[qt] = ATT_FWD_EXP2(m_run[qt] - m_new);
                     moved |= m_new > m_run[qt];
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                 }
             } else {
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < NQ; ++qt) {
                     float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
 #pragma unroll
                     for (int kt = 1; kt < 4; ++kt)
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
             }
             if (__any(moved)) {        // wave-uniform: after the first tiles the running max rarely moves, skip 34 multiplies
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < NQ; ++qt) {
                     lacc[qt] *= alpha[qt];
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha[qt];
@@ -488,16 +503,16 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
         constexpr int NKS = BKV / KSTEP;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            uint4 pb[2];
+            uint4 pb[NQ];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < NQ; ++qt) {
                 f32x4 tl[2];
                 tl[0] = sacc[ks * ET<T>::ACC_TILES][qt];
                 tl[1] = sacc[ks * ET<T>::ACC_TILES + ET<T>::ACC_TILES - 1][qt];
                 pb[qt] = acc_to_kfrag<T>(tl);
             }
-            ATT_FWD_MMA(ones_v, pb[0], lacc[0]);
-            ATT_FWD_MMA(ones_v, pb[1], lacc[1]);
+#pragma unroll
+            for (int qt = 0; qt < NQ; ++qt) ATT_FWD_MMA(ones_v, pb[qt], lacc[qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint4 a;
@@ -507,8 +522,8 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
                     a = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
                 else a = frag_kstrided<T>(Vnat, H::PITCH_N, ks * KSTEP, 16 * dt, lane);
-                ATT_FWD_MMA(a, pb[0], oacc[dt][0]);
-                ATT_FWD_MMA(a, pb[1], oacc[dt][1]);
+#pragma unroll
+                for (int qt = 0; qt < NQ; ++qt) ATT_FWD_MMA(a, pb[qt], oacc[dt][qt]);
             }
         }
         if (MODE == 2) {   // c[d] += sum_key mask[key] * V[key][d]; thread -> (d = tid & 63, 16 keys of this tile)
@@ -541,7 +556,7 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD_OCC) void attn_fwd_kernel(const At
         __syncthreads();
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < NQ; ++qt) {
         const float l = lacc[qt][0];          // the MFMA already summed over all keys (all lane groups)
         const int q = q0 + 16 * qt + i;
         if (q < S) {
@@ -1084,7 +1099,8 @@ static AttnP pack(const tav_attn_args* a) {
 }
 
 template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, hipStream_t st) {
-    dim3 grid((p.S + 127) / 128, p.nh, p.B);
+    constexpr int QW = 64 * fwd_nq<T, MODE, PRE>();          // queries per workgroup
+    dim3 grid((p.S + QW - 1) / QW, p.nh, p.B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, PRE>), grid, dim3(256), fwd_lds<T>(), st, p);
     return (int)hipGetLastError();
 }
