@@ -61,6 +61,13 @@ TAV_DEV int xcd_remap(int id, int total) {
 //    (85 FLOP/B, one 8-wave workgroup per CU) is faster wherever its coarser tile grid still fills the chip;
 //  * the tile count must divide well over the 256 CUs (M = 11712, N = 768: 552 tiles of 128 rows leave 28 % of the chip idle in
 //    the last round, 732 tiles of 96 rows do not) and small-M problems must still produce enough workgroups.
+// 3 + 2 image rings of the 256 x 256 tiles (see R25 in gemm_nt_kernel); 0 = two whole K-tile stages (rounds 1-2), kept for A/B builds
+#ifndef TAV_NT_RING25
+#define TAV_NT_RING25 1
+#endif
+#ifndef TAV_TN_RING25
+#define TAV_TN_RING25 1
+#endif
 enum { NT_GEN = 0, NT_PLAIN = 1, NT_RESID = 2, NT_GELU_D = 3, NT_MUL_D = 4 };   // epilogue flavours (see the epilogue)
 template <typename T, typename TO, int TM, int NST, int NW, int TNW, int EPI = NT_GEN>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmNT p) {
@@ -71,9 +78,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     constexpr int PB = BN / 8 / NW;                       // DMA pieces of the B image per wave (the A image: TM per wave)
     constexpr int NP = TM + PB;                           // DMA pieces per wave per K-tile
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128;   // bytes per K-tile image
+    // R25 (256 x 256 tile): the 160 KB of LDS hold FIVE 32 KB images -- three A slots and two B slots.  With two whole K-tile slots a DMA must
+    // be issued and land within ONE K-tile time and the ring is empty at every wait (the loop then runs at issue + round trip per K-tile: the
+    // MFMA-free build takes as long as the full one).  With the fifth image, A(kt+2) is issued while tile kt is multiplied: one image is still
+    // in flight at every wait, B(kt+1) goes out first in the iteration (most of a K-tile time to land), A(kt+2) has a K-tile time more.
+    constexpr bool R25 = (TAV_NT_RING25 != 0) && NW == 8 && TNW == 8 && NST == 2 && !F8 && ES == 2;
+    constexpr int NSA = R25 ? 3 : NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                  // [NST][BM][128B]  activations (m)
-    char* sB = smem + NST * TILE_A;   // [NST][BN][128B]  weights (n)
+    char* sA = smem;                  // [NSA][BM][128B]  activations (m)
+    char* sB = smem + NSA * TILE_A;   // [NST][BN][128B]  weights (n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -116,6 +129,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds_addr(sB) + wave * 8 * PB * 128);
     // piece pc of the next K-tile image: TM pieces of A, then PB of B.  The K offset rides on the SCALAR operand base (one 64-bit scalar add
     // per operand and K-tile); the lane offsets ga / gb never change, so a piece is {scalar add for the LDS address, M0, nop, DMA}.
+    auto stage_a = [&](int j, unsigned ko, int buf) { glds16_m0(Ab + ko, ga[j], ldsA + buf * TILE_A + j * 1024); };
+    auto stage_b = [&](int j, unsigned ko, int buf) { glds16_m0(Bb + ko, gb[j], ldsB + buf * TILE_B + j * 1024); };
     auto stage_piece = [&](int pc, unsigned ko, int buf) {
 #ifdef TAV_NT_DMA_OLD
         if (pc < TM) glds16_s(Ab, ga[pc] + ko, ldsA + buf * TILE_A + pc * 1024);
@@ -198,6 +213,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
                 for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
         }
     };
+    // R25 iteration: ISSUE_B = B(kt+1) goes out (kt + 1 < nk), ISSUE_A = A(kt+2) goes out (kt + 2 < nk).  Issue order per iteration: B(kt+1),
+    // then A(kt+2); at the next wait the TM youngest pieces are exactly A(kt+2)'s and may stay in flight.
+    auto ktile25 = [&](int kt, int ca, int cb, auto issue_b, auto issue_a) {
+        constexpr bool IB = decltype(issue_b)::value, IA = decltype(issue_a)::value;
+        if constexpr (IB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM) : "memory");   // A(kt+1) was issued after B(kt): it may still fly
+        else wait_vmcnt0();
+        __syncthreads();
+        const char* cA = sA + ca * TILE_A;
+        const char* cB = sB + cb * TILE_B;
+        const int na = ca == 0 ? 2 : ca - 1;                  // slot of A(kt-1) = slot of A(kt+2)
+        const int nb = cb ^ 1;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) fb0[t] = *reinterpret_cast<const uint4*>(cB + off_b[0][t]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa1[t] = *reinterpret_cast<const uint4*>(cA + off_a[1][t]);
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
+            if constexpr (IB || IA) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (IB) { if (tn < PB) stage_b(tn, (unsigned)(kt + 1) * 128u, nb); }
+                if constexpr (IA) { if (tn >= PB && tn - PB < TM) stage_a(tn - PB, (unsigned)(kt + 2) * 128u, na); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TNW; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb1[tn], fa1[tm], acc[tn][tm]);
+    };
+    if constexpr (R25) {
+        static_assert(!R25 || PB + TM <= TNW, "one DMA piece per MFMA group");
+#pragma unroll
+        for (int j = 0; j < TM; ++j) stage_a(j, 0u, 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) stage_b(j, 0u, 0);
+        if (nk > 1) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) stage_a(j, 128u, 1);
+        }
+        int ca = 0, cb = 0, kt = 0;
+        for (; kt + 2 < nk; ++kt) { ktile25(kt, ca, cb, std::true_type{}, std::true_type{}); ca = ca == 2 ? 0 : ca + 1; cb ^= 1; }
+        if (kt + 1 < nk) { ktile25(kt, ca, cb, std::true_type{}, std::false_type{}); ca = ca == 2 ? 0 : ca + 1; cb ^= 1; ++kt; }
+        if (kt < nk) ktile25(kt, ca, cb, std::false_type{}, std::false_type{});
+    } else {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) {
@@ -208,6 +274,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     int kt = 0;
     for (; kt + NST - 1 < nk; ++kt) { ktile(kt, cur, std::true_type{}); cur = cur + 1 == NST ? 0 : cur + 1; }
     for (; kt < nk; ++kt) { ktile(kt, cur, std::false_type{}); cur = cur + 1 == NST ? 0 : cur + 1; }
+    }
 
     // ---- epilogue.  Lane (g,i) holds C[m = .. + i][n = .. + 4g + r]: storing from that layout gives 32-B row segments and
     // uncoalesced residual reads.  Instead the f32 accumulator tile goes through the (now idle) staging LDS -- one ds_write_b128
@@ -693,32 +760,43 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
         }
     const unsigned strideA = (unsigned)(KT * p.lda * ES), strideB = (unsigned)(KT * p.ldb * ES);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 8 * ROWB);
-    auto stage = [&](int kt, int buf) {
-        const bool full = (kt + 1) * KT <= nrows;               // block-uniform
-        if (full) {
-            const unsigned ka = kt * strideA, kb = kt * strideB;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    glds16_m0(Ab0 + ka, offA[h][j], lds0 + buf * STAGE + h * SUB + j * 1024);
-                    glds16_m0(Bb0 + kb, offB[h][j], lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
-                }
-        } else {                                                    // ragged last K-tile: ordinary loads, zero fill
+    // LDS: FIVE 32 KB images (two [64][128] sub-images each) -- three dY slots and two X slots (TAV_TN_RING25; the NT kernel's ring, see there):
+    // dY(kt+2) is issued while tile kt is multiplied, X(kt+1) goes out first in the iteration.  Without the macro: two whole stages.
+    constexpr bool R25 = TAV_TN_RING25 != 0;
+    constexpr int NSA = R25 ? 3 : 2;
+    constexpr int IMG = 2 * SUB;                            // one operand's K-tile image (halves 0 / 1)
+    constexpr int OFF_B = NSA * IMG;                        // X images behind the dY images
+    // ragged last K-tile of one operand: ordinary loads, zero fill (block-uniform condition at the call sites)
+    auto stage_ragged = [&](int kt, int slot, bool is_b) {
 #pragma unroll 1
-            for (int e = 0; e < 4; ++e) {
-                const int h = e >> 1, j = e & 1;
-                const int trow = wave * 8 + j * 4 + lrow;
-                const int c = 16 * h + TT::sw(trow, lslot);
-                const bool ok = (kt * KT + trow) < nrows;
-                const long grow = (long)row_begin + kt * KT + trow;
-                uint4 va = make_uint4(0, 0, 0, 0), vb = va;
-                if (ok && c < a_cmax) va = *reinterpret_cast<const uint4*>(p.A + (grow * p.lda + n1_0) * ES + c * 16);
-                if (ok && c < b_cmax) vb = *reinterpret_cast<const uint4*>(p.B + (grow * p.ldb + n2_0) * ES + c * 16);
-                *reinterpret_cast<uint4*>(smem + buf * STAGE + h * SUB + trow * ROWB + lslot * 16) = va;
-                *reinterpret_cast<uint4*>(smem + buf * STAGE + (2 + h) * SUB + trow * ROWB + lslot * 16) = vb;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int h = e >> 1, j = e & 1;
+            const int trow = wave * 8 + j * 4 + lrow;
+            const int c = 16 * h + TT::sw(trow, lslot);
+            const bool ok = (kt * KT + trow) < nrows;
+            const long grow = (long)row_begin + kt * KT + trow;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (!is_b) { if (ok && c < a_cmax) v = *reinterpret_cast<const uint4*>(p.A + (grow * p.lda + n1_0) * ES + c * 16); }
+            else { if (ok && c < b_cmax) v = *reinterpret_cast<const uint4*>(p.B + (grow * p.ldb + n2_0) * ES + c * 16); }
+            *reinterpret_cast<uint4*>(smem + (is_b ? OFF_B : 0) + slot * IMG + h * SUB + trow * ROWB + lslot * 16) = v;
         }
+    };
+    // piece pc (0..3 = [half][instruction]) of an operand's K-tile image by LDS-DMA
+    auto piece_a = [&](int pc, unsigned ka, int slot) { glds16_m0(Ab0 + ka, offA[pc >> 1][pc & 1], lds0 + slot * IMG + (pc >> 1) * SUB + (pc & 1) * 1024); };
+    auto piece_b = [&](int pc, unsigned kb, int slot) { glds16_m0(Bb0 + kb, offB[pc >> 1][pc & 1], lds0 + OFF_B + slot * IMG + (pc >> 1) * SUB + (pc & 1) * 1024); };
+    const bool last_ragged = nk > 0 && nk * KT > nrows;     // only the last K-tile can be short
+    auto is_dma = [&](int kt) { return kt < nk && !(last_ragged && kt == nk - 1); };
+    auto stage_a = [&](int kt, int slot) {                  // whole image, up front (prologue / ragged tile)
+        if (is_dma(kt)) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) piece_a(pc, (unsigned)kt * strideA, slot);
+        } else stage_ragged(kt, slot, false);
+    };
+    auto stage_b = [&](int kt, int slot) {
+        if (is_dma(kt)) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) piece_b(pc, (unsigned)kt * strideB, slot);
+        } else stage_ragged(kt, slot, true);
     };
 
     f32x4 acc[4][8];  // [n1 tile][n2 tile]
@@ -730,23 +808,25 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
     const int bias_mod = p.bias_spread ? p.tiles_2 : 1, bias_rem = p.bias_spread ? t2 : 0;
     float bsum = 0.f;
 
-    // one DMA piece of the NEXT K-tile (8 per wave) -- issued between the MFMA groups of the first K-step: back to back right after the
-    // barrier they cost every wave of the CU ~1000 cycles of issue time at the same moment, with nothing on the matrix pipe
-    auto stage_piece = [&](int pc, unsigned ka, unsigned kb, int buf) {
-        const int h = (pc >> 1) & 1, j = pc >> 2;
-        if (pc & 1) glds16_m0(Bb0 + kb, offB[h][j], lds0 + buf * STAGE + (2 + h) * SUB + j * 1024);
-        else glds16_m0(Ab0 + ka, offA[h][j], lds0 + buf * STAGE + h * SUB + j * 1024);
-    };
-    if (nk > 0) stage(0, 0);
+    // The DMA pieces of later K-tiles (8 per wave and iteration) are issued between the MFMA groups of the first K-step: back to back right
+    // after the barrier they cost every wave of the CU ~1000 cycles of issue time at the same moment, with nothing on the matrix pipe.
+    // Iteration kt issues X(kt+1) [R25: and dY(kt+2); else dY(kt+1)]; issue order X then dY, so at the next wait the 4 youngest pieces are
+    // dY's and -- R25 -- may stay in flight.
+    constexpr int AHEAD_A = R25 ? 2 : 1;
+    if (nk > 0) { stage_a(0, 0); stage_b(0, 0); if (R25 && nk > 1) stage_a(1, 1); }
+    int ca = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        wait_vmcnt0();
+        const int cb = kt & 1;
+        if (R25 && is_dma(kt + 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else wait_vmcnt0();
         __syncthreads();
-        const bool next_full = (kt + 2) * KT <= nrows;          // block-uniform: the next tile exists and takes the DMA path
-        if (kt + 1 < nk && !next_full) stage(kt + 1, cur ^ 1);  // (ragged last tile: through registers, up front)
-        const unsigned ka = (unsigned)(kt + 1) * strideA, kb = (unsigned)(kt + 1) * strideB;
-        const char* cA = smem + cur * STAGE + (w1 >> 1) * SUB;
-        const char* cB = smem + cur * STAGE + (2 + w2) * SUB;
+        const int na = R25 ? (ca == 0 ? 2 : ca - 1) : (ca ^ 1), nb = cb ^ 1;      // slots of dY(kt + AHEAD_A), X(kt + 1)
+        const bool dma_b = is_dma(kt + 1), dma_a = is_dma(kt + AHEAD_A);          // block-uniform
+        if (kt + 1 < nk && !dma_b) stage_b(kt + 1, nb);                            // (ragged last tile: through registers, up front)
+        if (kt + AHEAD_A < nk && !dma_a) stage_a(kt + AHEAD_A, na);
+        const unsigned ka = (unsigned)(kt + AHEAD_A) * strideA, kb = (unsigned)(kt + 1) * strideB;
+        const char* cA = smem + ca * IMG + (w1 >> 1) * SUB;
+        const char* cB = smem + OFF_B + cb * IMG + w2 * SUB;
 #pragma unroll
         for (int s2 = 0; s2 < KT / KSTEP; ++s2) {
             uint4 f1[4], f2[8];
@@ -761,20 +841,22 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
                 for (int a = 0; a < 4; ++a) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
                 if (s2 == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (next_full) stage_piece(b, ka, kb, cur ^ 1);
+                    if (b < 4) { if (dma_b) piece_b(b, kb, nb); }
+                    else { if (dma_a) piece_a(b - 4, ka, na); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         if (do_bias && (kt % bias_mod) == bias_rem) {      // column (tid & 255) of the dY tile, token rows (tid >> 8) * 32 .. + 31
             const int col = tid & 255, cbyte = (col & 127) * ES;
-            const char* img = smem + cur * STAGE + (col >> 7) * SUB;
+            const char* img = smem + ca * IMG + (col >> 7) * SUB;
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) {
                 const int row = (tid >> 8) * 32 + r;
                 bsum += ET<T>::ld(reinterpret_cast<const T*>(img + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
             }
         }
+        ca = R25 ? (ca == 2 ? 0 : ca + 1) : (ca ^ 1);
     }
     __syncthreads();
 
@@ -945,7 +1027,8 @@ static double nt_small_us(int M, int N, double nk, int nz, int tm, int epi) {
     return (double)((long)((t + slots[tm] - 1) / slots[tm])) * (kt + fix[tm] + e * tm / 4.0);
 }
 static double nt_big_round_us(double nk, int epi) {
-    const double kt = (nk <= 36.0 ? nk : 36.0 + 1.33 * (nk - 36.0)) * 1.48;
+    // (3 + 2 ring: 1.37-1.52 us per K-tile at every K measured; with two whole stages K-tiles beyond the 36th cost a third more)
+    const double kt = TAV_NT_RING25 ? nk * 1.45 : (nk <= 36.0 ? nk : 36.0 + 1.33 * (nk - 36.0)) * 1.48;
     return kt + 6.5 + ((epi & 1) ? 9.0 : 0.0) + ((epi & 2) ? 4.0 : 0.0) + ((epi & 4) ? 3.0 : 0.0) + ((epi & 8) ? 4.7 : 0.0) + ((epi & 16) ? 6.7 : 0.0);
 }
 // Returns the tile for the launch; when `rows_big` is given and a mixed schedule is faster, *rows_big < M is the number of leading rows that
@@ -1060,7 +1143,8 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
         else if (nst < 2 || nst > 4) nst = (wgs <= 256 && in_dtype == TAV_BF16) ? 4 : 2;
         if (in_dtype != TAV_BF16) nst = 2;
         dim3 grid(p.tiles_m * p.tiles_n, nzb * p.nzg), block(tm >= 8 ? 512 : 256);
-        const size_t lds = (size_t)nst * (bm + bn) * 128;    // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB
+        // 256x128: 3 x 48 KB (its f32 epilogue tile needs 128 KB); 256x256: 2 x 64 KB, or 3 A + 2 B images = 160 KB (bf16, R25)
+        const size_t lds = (TAV_NT_RING25 && tm == 16 && in_dtype == TAV_BF16) ? (size_t)160 * 1024 : (size_t)nst * (bm + bn) * 128;
 #define TAV_NT_LAUNCH_S(TT, TOO, NS, EP)                                                                                 \
     do {                                                                                                                 \
         if (tm == 4) hipLaunchKernelGGL((gemm_nt_kernel<TT, TOO, 4, NS, 4, 4, EP>), grid, block, lds, stream, p);         \
@@ -1292,7 +1376,7 @@ extern "C" int tav_gemm_tn_grouped_ws(const tav_gemm_tn_problem* probs, int32_t 
         ws_off += (long)red.nbias[k] * probs[k].N1;
     }
     grp.n = nprob; red.n = nprob; red.nsplit = nsplit;
-    if (big) hipLaunchKernelGGL((gemm_tn_grouped_big_kernel<bf16>), dim3(total, nsplit), dim3(512), 2 * 4 * 64 * 256, stream, grp);
+    if (big) hipLaunchKernelGGL((gemm_tn_grouped_big_kernel<bf16>), dim3(total, nsplit), dim3(512), (TAV_TN_RING25 ? 5 : 4) * 2 * 64 * 256, stream, grp);
     else if (dtype == TAV_BF16) hipLaunchKernelGGL((gemm_tn_grouped_kernel<bf16>), dim3(total), dim3(256), 4 * 64 * 256, stream, grp);
     else hipLaunchKernelGGL((gemm_tn_grouped_kernel<float>), dim3(total), dim3(256), 4 * 64 * 512, stream, grp);
     if (nsplit > 1) hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)((end4 + 255) / 256)), dim3(256), 0, stream, red);

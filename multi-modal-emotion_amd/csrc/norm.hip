@@ -58,29 +58,55 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = p.W >> 2;
     const float invW = 1.f / (float)p.W;
-    f32x4 dg[LN_MAXV], db[LN_MAXV];
+    f32x4 dg[LN_MAXV], db[LN_MAXV], gam[LN_MAXV];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) { dg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+    for (int j = 0; j < LN_MAXV; ++j) {
+        dg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = lane + 64 * j;
+        gam[j] = c < nv ? ld4(p.gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};   // row invariant (the stores below may alias as far as the compiler knows)
+    }
+    // A wave walks its rows with the NEXT row's operands (x, dy, the residual gradient, mean / rstd) requested before the current row is
+    // reduced and stored: one row per wave in flight left the kernel at 4.2 TB/s (two workgroups per CU, ~6 KB per wave and round trip, nothing
+    // in flight during the two wave reductions and the stores); vmcnt retires in issue order, so the wait for a prefetched row never waits
+    // for the stores issued after it.
+    struct Row { f32x4 x[LN_MAXV], d[LN_MAXV], a[LN_MAXV]; float mean, rstd; };
+    auto load_row = [&](long row, Row& r) __attribute__((always_inline)) {
         const TX* xr = reinterpret_cast<const TX*>(p.x) + row * p.ld_x;
         const TDY* dyr = reinterpret_cast<const TDY*>(p.dy) + row * p.ld_dy;
-        const float mean = p.mean[row], rstd = p.rstd[row];
+        r.mean = p.mean[row]; r.rstd = p.rstd[row];
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nv) {
+                r.x[j] = ld4(xr + 4 * c);
+                r.d[j] = ld4(dyr + 4 * c);
+                if (p.dx_add) r.a[j] = ld4(p.dx_add + row * p.ld_dx + 4 * c);
+            }
+        }
+    };
+    const long stride = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * 4 + wave;
+    Row cur;
+    if (row < p.rows) load_row(row, cur);
+    for (; row < p.rows; row += stride) {
+        Row nxt;
+        if (row + stride < p.rows) load_row(row + stride, nxt);
+        const float mean = cur.mean, rstd = cur.rstd;
         f32x4 xh[LN_MAXV], gdy[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c = lane + 64 * j;
             if (c < nv) {
-                xh[j] = (ld4(xr + 4 * c) - mean) * rstd;
-                f32x4 d = ld4(dyr + 4 * c);
-                const f32x4 gam = ld4(p.gamma + 4 * c);
+                xh[j] = (cur.x[j] - mean) * rstd;
+                f32x4 d = cur.d[j];
                 if (p.act == 1) {
-                    const f32x4 z = xh[j] * gam + ld4(p.beta + 4 * c);
+                    const f32x4 z = xh[j] * gam[j] + ld4(p.beta + 4 * c);
                     d[0] *= gelu_grad_t<TL>(z[0]); d[1] *= gelu_grad_t<TL>(z[1]); d[2] *= gelu_grad_t<TL>(z[2]); d[3] *= gelu_grad_t<TL>(z[3]);
                 }
                 dg[j] += d * xh[j];
                 db[j] += d;
-                gdy[j] = d * gam;
+                gdy[j] = d * gam[j];
                 s1 += gdy[j][0] + gdy[j][1] + gdy[j][2] + gdy[j][3];
                 const f32x4 t = gdy[j] * xh[j];
                 s2 += t[0] + t[1] + t[2] + t[3];
@@ -92,11 +118,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnP p) {
             const int c = lane + 64 * j;
             if (c < nv) {
                 f32x4 dx = (gdy[j] - m1 - xh[j] * m2) * rstd;
-                if (p.dx_add) dx += ld4(p.dx_add + row * p.ld_dx + 4 * c);
+                if (p.dx_add) dx += cur.a[j];
                 if (p.dx_f32) st4(p.dx_f32 + row * p.ld_dx + 4 * c, dx);
                 if (p.dx_lp) st4(reinterpret_cast<TL*>(p.dx_lp) + row * p.ld_dx + 4 * c, dx);
             }
         }
+        cur = nxt;
     }
     if (!p.partials) return;
 #pragma unroll

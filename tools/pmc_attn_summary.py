@@ -2,6 +2,7 @@
 import collections
 import csv
 import glob
+import os
 import statistics
 import sys
 
@@ -11,9 +12,11 @@ dur = collections.defaultdict(list)
 for f in sorted(glob.glob(out + "/pass*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "attn_" not in k:
+        if os.environ.get("TAV_PMC_FILTER", "attn_") not in k:
             continue
         k = k.split("(")[0].replace("void tav::", "")
+        if "Grid_Size" in r and "gemm" in k:
+            k += f" grid {r['Grid_Size']}"
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "Start_Timestamp" in r and r["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_INSTS_VALU"):
             dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
