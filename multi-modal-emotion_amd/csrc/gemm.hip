@@ -10,7 +10,8 @@
 //
 // NT tiles: 64/96/128 x 128 (4 waves as 2x2, 2 workgroups per CU) or 256 x 256 (8 waves as 4x2, each a 64 x 128 block of 16x16 MFMA tiles, one
 // workgroup per CU), K-tile = 128 bytes per row (64 bf16 / 32 f32 / 128 e4m3), staged by LDS-DMA (global_load_lds_dwordx4 from inline asm) into a
-// 2- to 4-deep ring with the next tile's DMA pieces issued between the MFMA groups, one barrier per K-tile.  The host picks the tile -- or a mix of
+// 2- to 4-deep ring with the next tile's DMA pieces issued between the MFMA groups, one barrier per K-tile (the 256 x 256 tiles of both kernels:
+// five 32 KB images = 160 KB, three for the activation-side operand, which is issued two K-tiles ahead, two for the other).  The host picks the tile -- or a mix of
 // both over disjoint row ranges -- per call from a fitted cost model (nt_pick_tile, tav_gemm_nt_schedule) and the epilogue flavour (EPI) from the
 // arguments.  TN tiles: 128 x 128 (4 waves) or 256 x 256 (8 waves, token axis split into f32 slabs), 64-token K-tiles, transposed fragment reads.
 // LDS image of the NT kernel: [row][8 chunks of 16 B], chunk index XOR-swizzled with (row>>1)&7 so that the
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     // MFMA-free build takes as long as the full one).  With the fifth image, A(kt+2) is issued while tile kt is multiplied: one image is still
     // in flight at every wait, B(kt+1) goes out first in the iteration (most of a K-tile time to land), A(kt+2) has a K-tile time more.
     constexpr bool R25 = (TAV_NT_RING25 != 0) && NW == 8 && TNW == 8 && NST == 2 && !F8 && ES == 2;
-    constexpr int NSA = R25 ? 3 : NST;
+    constexpr bool B3 = TAV_NT_RING25 == 2;                // experiment: the third slot goes to B (weights) instead of A
+    constexpr int NSA = R25 ? (B3 ? 2 : 3) : NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                  // [NSA][BM][128B]  activations (m)
     char* sB = smem + NSA * TILE_A;   // [NST][BN][128B]  weights (n)
@@ -215,15 +217,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     };
     // R25 iteration: ISSUE_B = B(kt+1) goes out (kt + 1 < nk), ISSUE_A = A(kt+2) goes out (kt + 2 < nk).  Issue order per iteration: B(kt+1),
     // then A(kt+2); at the next wait the TM youngest pieces are exactly A(kt+2)'s and may stay in flight.
-    auto ktile25 = [&](int kt, int ca, int cb, auto issue_b, auto issue_a) {
-        constexpr bool IB = decltype(issue_b)::value, IA = decltype(issue_a)::value;
-        if constexpr (IB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM) : "memory");   // A(kt+1) was issued after B(kt): it may still fly
+    // (cl / cs: current slot of the three-slot operand / of the two-slot operand; issue_s: the two-slot operand's image of tile kt+1 goes
+    // out, issue_l: the three-slot operand's image of tile kt+2)
+    auto ktile25 = [&](int kt, int cl, int cs, auto issue_s, auto issue_l) {
+        constexpr bool IS = decltype(issue_s)::value, IL = decltype(issue_l)::value;
+        if constexpr (IS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B3 ? PB : TM) : "memory");   // long(kt+1) was issued after short(kt): it may still fly
         else wait_vmcnt0();
         __syncthreads();
-        const char* cA = sA + ca * TILE_A;
-        const char* cB = sB + cb * TILE_B;
-        const int na = ca == 0 ? 2 : ca - 1;                  // slot of A(kt-1) = slot of A(kt+2)
-        const int nb = cb ^ 1;
+        const char* cA = sA + (B3 ? cs : cl) * TILE_A;
+        const char* cB = sB + (B3 ? cl : cs) * TILE_B;
+        const int nl = cl == 0 ? 2 : cl - 1;                  // slot of long(kt-1) = slot of long(kt+2)
+        const int ns = cs ^ 1;
 #pragma unroll
         for (int t = 0; t < TM; ++t) fa0[t] = *reinterpret_cast<const uint4*>(cA + off_a[0][t]);
 #pragma unroll
@@ -233,14 +237,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
 #pragma unroll
         for (int t = 0; t < TNW; ++t) fb1[t] = *reinterpret_cast<const uint4*>(cB + off_b[1][t]);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int PS = B3 ? TM : PB, PL = B3 ? PB : TM;   // pieces of the short / long operand per wave
+#ifdef TAV_NT_DMA_EARLY
+        constexpr int PPG = 2;                                // pieces per MFMA group: everything issued in the first quarter
+#else
+        constexpr int PPG = 1;
+#endif
 #pragma unroll
         for (int tn = 0; tn < TNW; ++tn) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) TAV_NT_MMA(fb0[tn], fa0[tm], acc[tn][tm]);
-            if constexpr (IB || IA) {
+            if constexpr (IS || IL) {
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (IB) { if (tn < PB) stage_b(tn, (unsigned)(kt + 1) * 128u, nb); }
-                if constexpr (IA) { if (tn >= PB && tn - PB < TM) stage_a(tn - PB, (unsigned)(kt + 2) * 128u, na); }
+#pragma unroll
+                for (int q = tn * PPG; q < (tn + 1) * PPG; ++q) {
+                    if constexpr (IS) {
+                        if (q < PS) { if constexpr (B3) stage_a(q, (unsigned)(kt + 1) * 128u, ns); else stage_b(q, (unsigned)(kt + 1) * 128u, ns); }
+                    }
+                    if constexpr (IL) {
+                        if (q >= PS && q - PS < PL) { if constexpr (B3) stage_b(q - PS, (unsigned)(kt + 2) * 128u, nl); else stage_a(q - PS, (unsigned)(kt + 2) * 128u, nl); }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -251,18 +268,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     };
     if constexpr (R25) {
         static_assert(!R25 || PB + TM <= TNW, "one DMA piece per MFMA group");
+        auto stage_l = [&](unsigned ko, int slot) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) stage_a(j, 0u, 0);
+            for (int j = 0; j < (B3 ? PB : TM); ++j) { if constexpr (B3) stage_b(j, ko, slot); else stage_a(j, ko, slot); }
+        };
+        auto stage_s = [&](unsigned ko, int slot) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) stage_b(j, 0u, 0);
-        if (nk > 1) {
-#pragma unroll
-            for (int j = 0; j < TM; ++j) stage_a(j, 128u, 1);
-        }
-        int ca = 0, cb = 0, kt = 0;
-        for (; kt + 2 < nk; ++kt) { ktile25(kt, ca, cb, std::true_type{}, std::true_type{}); ca = ca == 2 ? 0 : ca + 1; cb ^= 1; }
-        if (kt + 1 < nk) { ktile25(kt, ca, cb, std::true_type{}, std::false_type{}); ca = ca == 2 ? 0 : ca + 1; cb ^= 1; ++kt; }
-        if (kt < nk) ktile25(kt, ca, cb, std::false_type{}, std::false_type{});
+            for (int j = 0; j < (B3 ? TM : PB); ++j) { if constexpr (B3) stage_a(j, ko, slot); else stage_b(j, ko, slot); }
+        };
+        stage_l(0u, 0);
+        stage_s(0u, 0);
+        if (nk > 1) stage_l(128u, 1);
+        int cl = 0, cs = 0, kt = 0;
+        for (; kt + 2 < nk; ++kt) { ktile25(kt, cl, cs, std::true_type{}, std::true_type{}); cl = cl == 2 ? 0 : cl + 1; cs ^= 1; }
+        if (kt + 1 < nk) { ktile25(kt, cl, cs, std::true_type{}, std::false_type{}); cl = cl == 2 ? 0 : cl + 1; cs ^= 1; ++kt; }
+        if (kt < nk) ktile25(kt, cl, cs, std::false_type{}, std::false_type{});
     } else {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
