@@ -20,6 +20,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = p.W >> 2;
     const float invW = 1.f / (float)p.W;
+    // (requesting the next row before this row's reductions, as ln_bwd_kernel does, made this kernel SLOWER: 33.5 -> 36.9 us at 46848 x 768 --
+    // with up to eight waves per SIMD and one row per wave in flight it already runs at 6.4 TB/s)
     for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
         const TX* xr = reinterpret_cast<const TX*>(p.x) + row * p.ld_x;
         f32x4 v[LN_MAXV];
@@ -201,17 +203,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { mean[k] = stats[((long)b * C + c + k) * 2]; rstd[k] = stats[((long)b * C + c + k) * 2 + 1]; gam[k] = gamma[c + k]; bet[k] = beta[c + k]; }
     }
-#pragma unroll 4
-    for (int t = t0 + rg; t < t1 && live; t += 4) {
-        const f32x4 v = ld4(x + ((long)b * Tn + t) * C + c);
+    auto one = [&](f32x4 v, f32x4 dyv) __attribute__((always_inline)) {
         if (!BWD) { a0 += v; a1 += v * v; }
         else {
-            const f32x4 xh = (v - mean) * rstd, dyv = ld4(dy + ((long)b * Tn + t) * C + c);
+            const f32x4 xh = (v - mean) * rstd;
             f32x4 dz;
 #pragma unroll
             for (int k = 0; k < 4; ++k) dz[k] = dyv[k] * gelu_grad_t<T>(xh[k] * gam[k] + bet[k]);
             a0 += dz; a1 += dz * xh;
         }
+    };
+    if (live) {
+        constexpr int UB = BWD ? 4 : 8;                      // rows requested before the first is used
+        const long rs = 4l * C;
+        long e = ((long)b * Tn + t0 + rg) * C + c;
+        int t = t0 + rg;
+        for (; t + 4 * (UB - 1) < t1; t += 4 * UB, e += UB * rs) {
+            f32x4 v[UB], d[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) { v[q] = ld4(x + e + q * rs); if (BWD) d[q] = ld4(dy + e + q * rs); else d[q] = v[q]; }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) one(v[q], d[q]);
+        }
+        for (; t < t1; t += 4, e += rs) one(ld4(x + e), BWD ? ld4(dy + e) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { red[rg][4 * cq + k][0] = a0[k]; red[rg][4 * cq + k][1] = a1[k]; }
@@ -237,40 +251,75 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, float* out, i
         out[idx * 2] = mean; out[idx * 2 + 1] = rsqrtf(var + eps);
     } else { out[idx * 2] = s0; out[idx * 2 + 1] = s1; }
 }
+// Apply passes: thread = 4 channels (one 8-B / 16-B access per row) x GN_AR rows at a stride of 4, so the per-(batch, channel) statistics
+// and the affine parameters are loaded ONCE per thread as float4s and four rows' loads are in flight per thread.  (One element quad per
+// thread with 12-24 scalar parameter loads beside its one useful load ran at 3.8 TB/s on the 524 MB activation.)
+constexpr int GN_AR = 16;        // rows per thread of the apply passes (a workgroup covers 4 * GN_AR rows x 256 channels)
 template <typename T>
-__global__ void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ stats, long n4, int Tn, int C) {
-    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i4 >= n4) return;
-    const int C4 = C >> 2, row = (int)(i4 / C4), c = ((int)i4 - row * C4) * 4, b = row / Tn;     // 32-bit index math
-    const long e = i4 * 4;
-    f32x4 v = ld4(x + e);
+__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ stats, int Tn, int C) {
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, b = blockIdx.z;
+    const int c = blockIdx.x * GN_CB + 4 * cq;
+    if (c >= C) return;
+    const f32x4 s0 = ld4(stats + ((long)b * C + c) * 2), s1 = ld4(stats + ((long)b * C + c) * 2 + 4);   // (mean, rstd) x 4 channels
+    const f32x4 mean = {s0[0], s0[2], s1[0], s1[2]}, gam = ld4(gamma + c), bet = ld4(beta + c);
+    const f32x4 sc = f32x4{s0[1], s0[3], s1[1], s1[3]} * gam;
+    const int t0 = blockIdx.y * (4 * GN_AR) + rg;
+    const long e0 = ((long)b * Tn + t0) * C + c, rs = 4l * C;                 // this thread's first element, elements per row step
+    if (t0 + 4 * (GN_AR - 1) < Tn) {                                          // whole block of rows: four rows' loads issued before the first use
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float* st = stats + ((long)b * C + c + k) * 2;
-        v[k] = gelu_t<T>((v[k] - st[0]) * st[1] * gamma[c + k] + beta[c + k]);
+        for (int r0 = 0; r0 < GN_AR; r0 += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ld4(x + e0 + (r0 + q) * rs);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 u = (v[q] - mean) * sc + bet;
+                u[0] = gelu_t<T>(u[0]); u[1] = gelu_t<T>(u[1]); u[2] = gelu_t<T>(u[2]); u[3] = gelu_t<T>(u[3]);
+                st4(y + e0 + (r0 + q) * rs, u);
+            }
+        }
+    } else {
+        for (int r = 0; r < GN_AR && t0 + 4 * r < Tn; ++r) {
+            f32x4 u = (ld4(x + e0 + r * rs) - mean) * sc + bet;
+            u[0] = gelu_t<T>(u[0]); u[1] = gelu_t<T>(u[1]); u[2] = gelu_t<T>(u[2]); u[3] = gelu_t<T>(u[3]);
+            st4(y + e0 + r * rs, u);
+        }
     }
-    st4(y + e, v);
 }
 template <typename T>
-__global__ void gn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ stats, const float* __restrict__ sums, long n4, int Tn, int C) {
-    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i4 >= n4) return;
-    const int C4 = C >> 2, row = (int)(i4 / C4), c = ((int)i4 - row * C4) * 4, b = row / Tn;
-    const long e = i4 * 4;
-    const f32x4 xv = ld4(x + e), dyv = ld4(dy + e);
-    f32x4 o;
+__global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, const float* __restrict__ sums, int Tn, int C) {
+    const int cq = threadIdx.x & 63, rg = threadIdx.x >> 6, b = blockIdx.z;
+    const int c = blockIdx.x * GN_CB + 4 * cq;
+    if (c >= C) return;
+    const f32x4 s0 = ld4(stats + ((long)b * C + c) * 2), s1 = ld4(stats + ((long)b * C + c) * 2 + 4);
+    const f32x4 m0 = ld4(sums + ((long)b * C + c) * 2), m1 = ld4(sums + ((long)b * C + c) * 2 + 4);     // (sum dz, sum dz * xhat) x 4 channels
     const float invT = 1.f / Tn;
+    const f32x4 mean = {s0[0], s0[2], s1[0], s1[2]}, rstd = {s0[1], s0[3], s1[1], s1[3]}, gam = ld4(gamma + c), bet = ld4(beta + c);
+    const f32x4 k0 = f32x4{m0[0], m0[2], m1[0], m1[2]} * invT, k1 = f32x4{m0[1], m0[3], m1[1], m1[3]} * invT, og = rstd * gam;
+    const int t0 = blockIdx.y * (4 * GN_AR) + rg;
+    const long e0 = ((long)b * Tn + t0) * C + c, rs = 4l * C;
+    auto one = [&](f32x4 xv, f32x4 dyv, long e) __attribute__((always_inline)) {
+        const f32x4 xh = (xv - mean) * rstd, z = xh * gam + bet;
+        f32x4 dz;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float* st = stats + ((long)b * C + c + k) * 2;
-        const float* sm = sums + ((long)b * C + c + k) * 2;
-        const float xh = (xv[k] - st[0]) * st[1], gam = gamma[c + k];
-        const float dz = dyv[k] * gelu_grad_t<T>(xh * gam + beta[c + k]);
-        o[k] = st[1] * gam * (dz - sm[0] * invT - xh * sm[1] * invT);
+        for (int k = 0; k < 4; ++k) dz[k] = dyv[k] * gelu_grad_t<T>(z[k]);
+        st4(dx + e, og * (dz - k0 - xh * k1));
+    };
+    if (t0 + 4 * (GN_AR - 1) < Tn) {
+#pragma unroll
+        for (int r0 = 0; r0 < GN_AR; r0 += 4) {
+            f32x4 xv[4], dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xv[q] = ld4(x + e0 + (r0 + q) * rs); dv[q] = ld4(dy + e0 + (r0 + q) * rs); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) one(xv[q], dv[q], e0 + (r0 + q) * rs);
+        }
+    } else {
+        for (int r = 0; r < GN_AR && t0 + 4 * r < Tn; ++r) one(ld4(x + e0 + r * rs), ld4(dy + e0 + r * rs), e0 + r * rs);
     }
-    st4(dx + e, o);
 }
 __global__ void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,13 +419,13 @@ extern "C" int tav_gn_gelu_fwd(const void* x, void* y, int32_t dtype, const floa
     if (B <= 0 || T <= 0 || C <= 0 || C % 64) return TAV_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tav_cdiv(C, GN_CB), GN_SPLIT, (unsigned)B);
-    const long n4 = B * T * C / 4;
+    const dim3 agrid((unsigned)tav_cdiv(C, GN_CB), (unsigned)tav_cdiv(T, 4 * GN_AR), (unsigned)B);
     if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_stats_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)nullptr, gamma, beta, stats, workspace, (int)T, (int)C);
     else if (dtype == TAV_F32) hipLaunchKernelGGL((gn_stats_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, gamma, beta, stats, workspace, (int)T, (int)C);
     else return TAV_ERR_DTYPE;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tav_cdiv(B * C, 256)), dim3(256), 0, st, workspace, stats, (int)T, (int)C, (int)B, eps, 1);
-    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, stats, n4, (int)T, (int)C);
-    else hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, stats, n4, (int)T, (int)C);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_fwd_kernel<bf16>), agrid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, stats, (int)T, (int)C);
+    else hipLaunchKernelGGL((gn_apply_fwd_kernel<float>), agrid, dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, stats, (int)T, (int)C);
     return (int)hipGetLastError();
 }
 
@@ -386,15 +435,15 @@ extern "C" int tav_gn_gelu_bwd(const void* x, const void* dy, void* dx, int32_t 
     if (B <= 0 || T <= 0 || C <= 0 || C % 64) return TAV_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tav_cdiv(C, GN_CB), GN_SPLIT, (unsigned)B);
-    const long n4 = B * T * C / 4;
+    const dim3 agrid((unsigned)tav_cdiv(C, GN_CB), (unsigned)tav_cdiv(T, 4 * GN_AR), (unsigned)B);
     float* sums = workspace + B * GN_SPLIT * C * 2;
     if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_stats_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, gamma, beta, stats, workspace, (int)T, (int)C);
     else if (dtype == TAV_F32) hipLaunchKernelGGL((gn_stats_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, gamma, beta, stats, workspace, (int)T, (int)C);
     else return TAV_ERR_DTYPE;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tav_cdiv(B * C, 256)), dim3(256), 0, st, workspace, sums, (int)T, (int)C, (int)B, 0.f, 0);
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(tav_cdiv(C, 256)), dim3(256), 0, st, sums, dgamma, dbeta, (int)B, (int)C, accumulate);
-    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, gamma, beta, stats, sums, n4, (int)T, (int)C);
-    else hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), dim3(tav_cdiv(n4, 256)), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, gamma, beta, stats, sums, n4, (int)T, (int)C);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((gn_apply_bwd_kernel<bf16>), agrid, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, (bf16*)dx, gamma, beta, stats, sums, (int)T, (int)C);
+    else hipLaunchKernelGGL((gn_apply_bwd_kernel<float>), agrid, dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, gamma, beta, stats, sums, (int)T, (int)C);
     return (int)hipGetLastError();
 }
 

@@ -144,6 +144,17 @@ if "ln" in what:          # LayerNorm backward (with dgamma/dbeta) at the four b
         dy = torch.randn(rows, 768, device=dev)
         lo, med = timeit(lambda: ops.ln_bwd(dy, x, g, bt, mean, rstd, want_f32=True, lp_dtype=torch.bfloat16))
         print(f"[{tag}] ln_bwd {name:7s} rows={rows:6d}: min {lo:6.1f} us  med {med:6.1f} us")
+        lo, med = timeit(lambda: ops.ln_fwd(x, g, bt, 1e-12, want_f32=False, lp_dtype=torch.bfloat16))
+        print(f"[{tag}] ln_fwd {name:7s} rows={rows:6d}: min {lo:6.1f} us  med {med:6.1f} us")
+if "gn" in what:          # wav2vec2 front-end GroupNorm + GELU over the conv0 output [B, 15999, 512] (bf16), forward and backward
+    x = rnd(B, 15999, 512)
+    g, bt = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+    y, stats = ops.gn_gelu_fwd(x, g, bt, 1e-5)
+    dy = rnd(B, 15999, 512)
+    lo, med = timeit(lambda: ops.gn_gelu_fwd(x, g, bt, 1e-5), iters=20, reps=5)
+    print(f"[{tag}] gn_gelu fwd (stats + finalize + apply) B={B}: min {lo:6.1f} us  med {med:6.1f} us")
+    lo, med = timeit(lambda: ops.gn_gelu_bwd(x, dy, g, bt, stats), iters=20, reps=5)
+    print(f"[{tag}] gn_gelu bwd (stats + finalize + param grads + apply) B={B}: min {lo:6.1f} us  med {med:6.1f} us")
 if "adamw" in what:       # fused clip + AdamW over a BERT-base-like parameter list (110 M parameters)
     from tav_amd.optim import FusedAdamW
     shapes = [(30522, 768)] + [(768, 768)] * 48 + [(3072, 768)] * 12 + [(768, 3072)] * 12 + [(768,)] * 100 + [(3072,)] * 12
