@@ -185,10 +185,11 @@ class AudioEncoder(nn.Module):
         else:
             B, T, C = h.shape
             h = E.layer_norm_lp(ectx, h.view(B * T, C), L0.layer_norm.weight, L0.layer_norm.bias, 1e-5, act=1).view(B, T, C)
+        u = None                                              # pre-activation of the producing conv layer (chains the GELU backward into col2im)
         for i in range(1, len(layers)):
             L = layers[i]
             fuse_gelu = c["feat_norm"] == "group"
-            h = E.ConvGemmFn.apply(h, L.conv.weight, L.conv.bias, c["conv_stride"][i], fuse_gelu, ectx)
+            h, u = E.ConvGemmFn.apply(h, u, L.conv.weight, L.conv.bias, c["conv_stride"][i], fuse_gelu, ectx)
             if not fuse_gelu:
                 B, T, C = h.shape
                 h = E.layer_norm_lp(ectx, h.view(B * T, C), L.layer_norm.weight, L.layer_norm.bias, 1e-5, act=1).view(B, T, C)

@@ -709,10 +709,15 @@ class GroupNormGeluFn(torch.autograd.Function):
 
 class ConvGemmFn(torch.autograd.Function):
     """Conv1d(C_in, C_out, k, stride) on channels-last [B, T_in, C_in] as one NT GEMM over overlapping rows
-    (lda = stride*C_in, K = k*C_in), optional bias and fused exact GELU; gradients: TN GEMM (dW), NT GEMM + col2im (dx)."""
+    (lda = stride*C_in, K = k*C_in), optional bias and fused exact GELU; gradients: TN GEMM (dW), NT GEMM + col2im (dx).
+
+    Returns (y, pre): `pre` is the pre-activation when `gelu` (else None).  A following conv layer passes it back as `u_in`
+    (then x must be gelu(u_in), the producer's y): its backward folds gelu'(u_in) into the col2im pass and hands the result to the
+    producer through `pre`'s gradient, so the chain of the wav2vec2 feature extractor (HF wav2vec2:382-419) runs no separate
+    GELU-backward pass between the layers."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, gelu, ectx):
+    def forward(ctx, x, u_in, w, b, stride, gelu, ectx):
         x = _c(x)
         B, T_in, Ci = x.shape
         Co, _, k = w.shape
@@ -722,26 +727,36 @@ class ConvGemmFn(torch.autograd.Function):
                           nzb=B, a_zb=T_in * Ci, c_zb=T_out * Co, out_shape=(B, T_out, Co))
         y, pre = res if gelu else (res, None)
         ctx.ectx, ctx.geom, ctx.has_b = ectx, (B, T_in, Ci, Co, k, stride, T_out), b is not None
-        ctx.save_for_backward(x, w, pre)
-        return y
+        ctx.chained = u_in is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, w, pre, u_in)
+        return y, pre
 
     @staticmethod
-    def backward(ctx, g):
-        x, w, pre = ctx.saved_tensors
+    def backward(ctx, g, g_pre):
+        x, w, pre, u_in = ctx.saved_tensors
         B, T_in, Ci, Co, k, stride, T_out = ctx.geom
-        g = _c(g)
-        du = ops.gelu_bwd(pre, g) if pre is not None else g
+        du = _c(g_pre) if g_pre is not None else None          # from a chained consumer: already times gelu'(pre)
+        if g is not None:
+            d2 = ops.gelu_bwd(pre, _c(g)) if pre is not None else _c(g)
+            du = d2 if du is None else du + d2
+        if du is None:
+            return None, None, None, None, None, None, None
         _, w_t = ctx.ectx.cache.conv(w)
-        dw = db = dx = None
-        if ctx.needs_input_grad[1]:
+        dw = db = dx = dui = None
+        if ctx.needs_input_grad[2]:
             dw = ops.gemm_tn(du, x, N1=Co, N2=k * Ci, lda=Co, ldb=stride * Ci, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Co, b_zb=T_in * Ci,
                              perm_inner=Ci, perm_outer=k, out_shape=(Co, Ci, k))
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if ctx.has_b and ctx.needs_input_grad[3]:
             db = ops.colsum(du.view(B * T_out, Co))
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[1] if ctx.chained else ctx.needs_input_grad[0]:
             dcol = ops.gemm_nt(du.view(B * T_out, Co), w_t, out_shape=(B * T_out, k * Ci))
-            dx = ops.col2im_1d(dcol, B, T_in, T_out, Ci, k, stride)
-        return dx, dw, db, None, None, None
+            d = ops.col2im_1d(dcol, B, T_in, T_out, Ci, k, stride, pre_act=u_in if ctx.chained else None)
+            if ctx.chained:
+                dui = d
+            else:
+                dx = d
+        return dx, dui, dw, db, None, None, None
 
 
 class PosConvFn(torch.autograd.Function):
