@@ -431,7 +431,7 @@ def main():
                 secondary["preset_A"] = {"utterances_per_s": round(b * args.steps / el, 2), "ms_per_step": round(el / args.steps * 1e3, 3),
                                          "workload": f"preset A ({describe(cfg_a)}), global batch {b}, same input shapes, {gf_a:.1f} GFLOP forward per utterance",
                                          "mfma_util_whole_step": round(3 * gf_a * 1e9 * b / (el / args.steps) / (MFMA_PEAK_BF16_TFLOPS * 1e12), 4),
-                                         "final_loss": round(float(loss_a), 5)}
+                                         "final_loss": round(float(loss_a.detach()), 5)}
                 del ga, step_a, pre_a, model_a, inp_a, lab_a
                 torch.cuda.empty_cache()
         except Exception as e:
@@ -449,10 +449,14 @@ def main():
         stepper.opt.zero_grad()
         ms_default = runtime.multistream[0]
         runtime.multistream[0] = False
-        eager_step()                                         # shapes may have changed (secondary batch): re-warm
-        ops.profile_start(("gemm_nt", "gemm_tn", "attn", "ln"))
-        for _ in range(2):
-            eager_step()
+        # (on the stream the step was captured on: the parameters' AccumulateGrad nodes were created there, and autograd synchronises -- and
+        # warns -- when a gradient arrives from another stream)
+        work_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(work_stream):
+            eager_step()                                     # shapes may have changed (secondary batch): re-warm
+            ops.profile_start(("gemm_nt", "gemm_tn", "attn", "ln"))
+            for _ in range(2):
+                eager_step()
         torch.cuda.synchronize()
         flops, secs, launches = ops.profile_stop("fp8" if args.dtype.startswith("fp8") else "bf16")
         runtime.multistream[0] = ms_default
