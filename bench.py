@@ -449,14 +449,16 @@ def main():
         stepper.opt.zero_grad()
         ms_default = runtime.multistream[0]
         runtime.multistream[0] = False
-        # (on the stream the step was captured on: the parameters' AccumulateGrad nodes were created there, and autograd synchronises -- and
-        # warns -- when a gradient arrives from another stream)
-        work_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(work_stream):
-            eager_step()                                     # shapes may have changed (secondary batch): re-warm
-            ops.profile_start(("gemm_nt", "gemm_tn", "attn", "ln"))
-            for _ in range(2):
-                eager_step()
+        # The captured step's autograd graph (kept alive by its static loss) holds the parameters' AccumulateGrad nodes, each tied to the
+        # BRANCH stream of its first backward; this pass runs every branch on one stream, and autograd would synchronise -- and warn -- on
+        # every such gradient.  Release the captured graph first: the nodes are re-created on this pass's stream.
+        graph = static_loss = loss = None                    # noqa: F841
+        import gc
+        gc.collect()
+        eager_step()                                         # shapes may have changed (secondary batch): re-warm
+        ops.profile_start(("gemm_nt", "gemm_tn", "attn", "ln"))
+        for _ in range(2):
+            eager_step()
         torch.cuda.synchronize()
         flops, secs, launches = ops.profile_stop("fp8" if args.dtype.startswith("fp8") else "bf16")
         runtime.multistream[0] = ms_default
