@@ -169,6 +169,15 @@ typedef struct tav_attn_args {
 } tav_attn_args;
 int tav_attn_fwd(const tav_attn_args* args, void* stream);
 int tav_attn_bwd(const tav_attn_args* args, void* stream);
+/* Slow-path helpers for VideoMAEEncoder.forward(head_mask=, output_attentions=True) (reference utils/TAVFormer.py:190, :368-370, :389; never
+ * used by the reference's training loop).  tav_attn_probs materialises, from q, k and the lse tav_attn_fwd wrote,
+ *   probs[b][h][i][j] = head_scale[b*hs_bstride + h] * softmax_j(scale q_i.k_j (+ key_mask[b][j], mask_mode 1)) (+ key_mask[b][j], mask_mode 2)
+ * as f32 [B][nheads][S][S] (head_scale NULL = 1; hs_bstride 0: one factor per head, nheads: per batch entry and head).
+ * tav_head_scale: out[r][h*64+d] = (a ? a[r][h*64+d] : 0) + (c0 + (head_scale ? head_scale[(r/S)*hs_bstride + h] : 0)) * b[r][h*64+d], r < B*S:
+ * the head-masked context  o + (m_h - 1) o_soft  (c0 = -1, a = o, b = o_soft), its gradient factors, and plain sums (head_scale NULL, c0 = 1). */
+int tav_attn_probs(const tav_attn_args* args, float* probs, const float* head_scale, int64_t hs_bstride, void* stream);
+int tav_head_scale(const void* a, const void* b, void* out, int32_t dtype, const float* head_scale, int64_t hs_bstride, float c0, int64_t B, int64_t S,
+                   int64_t nheads, int64_t lda, int64_t ldb, int64_t ldo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis (width W <= 1024, W % 4 == 0), one wave per row, f32 statistics.

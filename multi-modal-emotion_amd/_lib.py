@@ -82,6 +82,8 @@ _SIGS = {
     "tav_allreduce_bucket": (C.c_int, [vp, i64, i32, vp, vp]),
     "tav_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
     "tav_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), vp]),
+    "tav_attn_probs": (C.c_int, [C.POINTER(AttnArgs), vp, vp, i64, vp]),
+    "tav_head_scale": (C.c_int, [vp, vp, vp, i32, vp, i64, f32, i64, i64, i64, i64, i64, i64, vp]),
     "tav_ln_fwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd_partials": (C.c_int, [i64]),

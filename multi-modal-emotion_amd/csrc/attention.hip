@@ -1062,6 +1062,52 @@ template <typename T, int MODE, bool PRE> constexpr size_t dkdv_lds() {
 }
 template <typename T> constexpr size_t dq_lds() { return 2 * (2 * 64 * HD<T>::ROWB + (HD<T>::DUAL ? 0 : 64 * HD<T>::PITCH_N) + 64 * 4); }
 
+// ------------------------------------------------------------------------------------------------
+// Slow-path helpers for two options of the fusion encoder that its training loop never uses (reference utils/TAVFormer.py:190, :368-370,
+// :389): the attention probabilities as a tensor (output_attentions) and a per-head factor on the softmax part of the context (head_mask).
+// Plain VALU kernels; the flash kernels above stay the product path and supply lse.
+//   probs[b][h][i][j] = hs[b][h] * exp(scale * q_i.k_j (+ mask_j, mode 1) - lse_i) (+ mask_j, mode 2)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const AttnP p, float* __restrict__ probs, const float* __restrict__ hs, int hs_bstride, int mode) {
+    constexpr int ES = ET<T>::ES;
+    constexpr float L2E = 1.4426950408889634f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;             // (b, head, i)
+    if (row >= (long)p.B * p.nh * p.S) return;
+    const int i = (int)(row % p.S), head = (int)((row / p.S) % p.nh), b = (int)(row / ((long)p.S * p.nh));
+    const T* qr = reinterpret_cast<const T*>(p.q + ((long)(b * p.S + i) * p.ld_q + head * 64) * ES);
+    f32x4 qv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) qv[t] = ld4(qr + 4 * t);     // the same address in every lane: one broadcast fetch
+    const float c = p.pre ? 1.f : p.scale * L2E;
+    const float l2 = p.lse[((long)b * p.nh + head) * p.S + i] * L2E;
+    const float f = hs ? hs[(long)b * hs_bstride + head] : 1.f;
+    for (int j = lane; j < p.S; j += 64) {
+        const T* kr = reinterpret_cast<const T*>(p.k + ((long)(b * p.S + j) * p.ld_k + head * 64) * ES);
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const f32x4 kv = ld4(kr + 4 * t); dot += qv[t][0] * kv[0] + qv[t][1] * kv[1] + qv[t][2] * kv[2] + qv[t][3] * kv[3]; }
+        float s2 = dot * c;
+        if (mode == 1) s2 += p.mask[(long)b * p.S + j] * L2E;
+        float pr = exp2f(s2 - l2) * f;
+        if (mode == 2) pr += p.mask[(long)b * p.S + j];
+        probs[row * p.S + j] = pr;
+    }
+}
+//   out[r][h*64 + d] = (a ? a[r][...] : 0) + (c0 + (hs ? hs[b][h] : 0)) * b[r][...]        r = b*S + s
+template <typename T>
+__global__ void head_scale_kernel(const T* __restrict__ a, const T* __restrict__ bsrc, T* __restrict__ out, const float* __restrict__ hs, int hs_bstride,
+                                  float c0, long n4, int S, int nh, long lda, long ldb, long ldo) {
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= n4) return;
+    const long row = i4 / (nh * 16);
+    const int col4 = (int)(i4 - row * (nh * 16)), head = col4 >> 4;
+    const float f = c0 + (hs ? hs[(row / S) * hs_bstride + head] : 0.f);
+    f32x4 v = ld4(bsrc + row * ldb + 4 * col4) * f;
+    if (a) v += ld4(a + row * lda + 4 * col4);
+    st4(out + row * ldo + 4 * col4, v);
+}
+
 static int check(const tav_attn_args* a, bool bwd) {
     if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse) return TAV_ERR_NULL;
     if (a->B <= 0 || a->S <= 0 || a->nheads <= 0) return TAV_ERR_SHAPE;
@@ -1138,4 +1184,34 @@ extern "C" int tav_attn_bwd(const tav_attn_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == TAV_BF16) return p.pre ? dispatch_bwd<bf16, true>(p, a->mask_mode, st) : dispatch_bwd<bf16, false>(p, a->mask_mode, st);
     return p.pre ? dispatch_bwd<float, true>(p, a->mask_mode, st) : dispatch_bwd<float, false>(p, a->mask_mode, st);
+}
+
+extern "C" int tav_attn_probs(const tav_attn_args* a, float* probs, const float* head_scale, int64_t hs_bstride, void* stream) {
+    if (!a || !a->q || !a->k || !a->lse || !probs) return TAV_ERR_NULL;
+    if (a->B <= 0 || a->S <= 0 || a->nheads <= 0 || hs_bstride < 0) return TAV_ERR_SHAPE;
+    if (a->dtype != TAV_BF16 && a->dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if (a->mask_mode < 0 || a->mask_mode > 2) return TAV_ERR_SHAPE;
+    if (a->mask_mode != 0 && !a->key_mask) return TAV_ERR_NULL;
+    const int pk = a->dtype == TAV_BF16 ? 8 : 4;
+    if (a->ld_q % pk || a->ld_k % pk) return TAV_ERR_ALIGN;
+    const AttnP p = pack(a);
+    const long rows = (long)p.B * p.nh * p.S;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == TAV_BF16) hipLaunchKernelGGL((attn_probs_kernel<bf16>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, probs, head_scale, (int)hs_bstride, (int)a->mask_mode);
+    else hipLaunchKernelGGL((attn_probs_kernel<float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, probs, head_scale, (int)hs_bstride, (int)a->mask_mode);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tav_head_scale(const void* a, const void* b, void* out, int32_t dtype, const float* head_scale, int64_t hs_bstride, float c0, int64_t B,
+                              int64_t S, int64_t nheads, int64_t lda, int64_t ldb, int64_t ldo, void* stream) {
+    if (!b || !out) return TAV_ERR_NULL;
+    if (B <= 0 || S <= 0 || nheads <= 0 || hs_bstride < 0) return TAV_ERR_SHAPE;
+    if (dtype != TAV_BF16 && dtype != TAV_F32) return TAV_ERR_DTYPE;
+    if (lda % 4 || ldb % 4 || ldo % 4) return TAV_ERR_ALIGN;
+    const long n4 = B * S * nheads * 16;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((head_scale_kernel<bf16>), grid, block, 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, head_scale, (int)hs_bstride, c0, n4, (int)S, (int)nheads, (long)lda, (long)ldb, (long)ldo);
+    else hipLaunchKernelGGL((head_scale_kernel<float>), grid, block, 0, st, (const float*)a, (const float*)b, (float*)out, head_scale, (int)hs_bstride, c0, n4, (int)S, (int)nheads, (long)lda, (long)ldb, (long)ldo);
+    return (int)hipGetLastError();
 }

@@ -228,8 +228,12 @@ def _DGRAD_OUT(pol):
 
 # ---------------------------------------------------------------------------------------------- encoder layer
 class LayerSpec:
-    def __init__(self, B, S, nheads, eps, pre_ln, mask_mode=0, branch=None):
+    def __init__(self, B, S, nheads, eps, pre_ln, mask_mode=0, branch=None, head_scale=None, probs_out=None):
         self.B, self.S, self.nheads, self.eps, self.pre_ln, self.mask_mode, self.branch = B, S, nheads, eps, pre_ln, mask_mode, branch
+        # slow-path options of the fusion encoder (reference utils/TAVFormer.py:190, :368-370, :389; never set by the training loop):
+        # head_scale: f32 [nheads] / [B, nheads] factor on the softmax part of the context (head_mask); probs_out: list that receives the
+        # layer's attention probabilities [B, nheads, S, S] f32 (output_attentions; detached)
+        self.head_scale, self.probs_out = head_scale, probs_out
 
 
 GROUPED_WGRAD = [os.environ.get("TAV_GROUPED_WGRAD", "1") == "1"]
@@ -285,7 +289,18 @@ class EncoderLayerFn(torch.autograd.Function):
             mean1 = rstd1 = None
         qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
         o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
-        y1 = ops.gemm_nt(o, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
+        hs, o_ctx = spec.head_scale, o
+        if hs is not None:                                      # head_mask: context = m_h * softmax(s) v (+ the rank-1 mask term, unscaled)
+            if spec.mask_mode == 2:
+                o_ctx = ops.head_scale(o, aux[1], hs, -1.0, B, S, nh)
+            elif spec.mask_mode == 0:
+                o_ctx = ops.head_scale(None, o, hs, 0.0, B, S, nh)
+            else:
+                raise NotImplementedError("head_mask with a pre-softmax key mask is not on any path of the reference")
+        if spec.probs_out is not None:
+            spec.probs_out.append(ops.attn_probs(qkv[:, :H], qkv[:, H:2 * H], lse, B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode,
+                                                 q_prescaled=QSC is not None, head_scale=hs))
+        y1 = ops.gemm_nt(o_ctx, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
         if spec.pre_ln:
             x1 = y1
             _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
@@ -304,7 +319,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.has = [p is not None for p in params]
         corr, o_soft = aux
         ctx.save_for_backward(x if spec.pre_ln else None, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2 if not spec.pre_ln else None,
-                              mean1, rstd1, mean2, rstd2, key_mask, *params)
+                              mean1, rstd1, mean2, rstd2, key_mask, o_ctx if hs is not None else None, hs, *params)
         if x2_lp is None or pol.f32:
             x2_lp = x2.new_empty(0)
         ctx.mark_non_differentiable(x2_lp)
@@ -314,8 +329,8 @@ class EncoderLayerFn(torch.autograd.Function):
     def backward(ctx, g2, _g_lp):
         pol, cache, spec = ctx.ectx.pol, ctx.ectx.cache, ctx.spec
         sv = ctx.saved_tensors
-        x, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2, mean1, rstd1, mean2, rstd2, key_mask = sv[:17]
-        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[17:]
+        x, a, qkv, o, lse, corr, o_soft, y1, c, u, h, y2, mean1, rstd1, mean2, rstd2, key_mask, o_ctx, hs = sv[:19]
+        (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[19:]
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
         _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
@@ -340,8 +355,19 @@ class EncoderLayerFn(torch.autograd.Function):
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
         # attention
         do = ops.gemm_nt(dy1_lp, wo_t)
-        dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
-                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
+        qs, ks, vs, pre = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], QSC is not None
+        if hs is None:
+            dqkv = ops.attn_bwd(qs, ks, vs, o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
+                                B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=pre)
+        elif spec.mask_mode == 2:
+            # context = o + (m_h - 1) o_soft: the whole of dO goes through the usual backward, (m_h - 1) dO once more through the softmax part alone
+            dqkv = ops.attn_bwd(qs, ks, vs, o, do, lse, (corr, o_soft), B, S, nh, key_mask=key_mask, mask_mode=2, q_prescaled=pre)
+            dqkv2 = ops.attn_bwd(qs, ks, vs, o_soft, ops.head_scale(None, do, hs, -1.0, B, S, nh), lse, None, B, S, nh, mask_mode=0, q_prescaled=pre)
+            ops.head_scale(dqkv, dqkv2, None, 1.0, B, S, 3 * nh, out=dqkv)
+        else:                                                   # context = m_h o
+            dqkv = ops.attn_bwd(qs, ks, vs, o, ops.head_scale(None, do, hs, 0.0, B, S, nh), lse, None, B, S, nh, mask_mode=0, q_prescaled=pre)
+        if hs is not None:
+            o = o_ctx                                           # what the out-projection multiplied (its weight gradient below)
         if spec.pre_ln:
             da = ops.gemm_nt(dqkv, wqkv_t, out_dtype=_DGRAD_OUT(pol))
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON and not pol.f32)
@@ -494,6 +520,8 @@ def encoder_layer(ectx, spec, x, x_lp, key_mask, params):
         x2, _ = EncoderLayerFn.apply(x, None, key_mask, _f32_ctx[0], spec, *params)
         return x2, None
     fn = EncoderLayerFp8Fn if (ectx.pol.fp8 and spec.branch in ectx.pol.fp8_stacks) else EncoderLayerFn
+    if fn is EncoderLayerFp8Fn and (spec.head_scale is not None or spec.probs_out is not None):
+        raise NotImplementedError("head_mask / output_attentions are built for the bf16 and fp32 policies only")
     x2, x2_lp = fn.apply(x, x_lp, key_mask, ectx, spec, *params)
     return x2, (x2_lp if x2_lp.numel() else None)
 

@@ -285,6 +285,27 @@ def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_m
     return dqkv
 
 
+def attn_probs(q, k, lse, B, S, nheads, *, key_mask=None, mask_mode=0, scale=0.125, q_prescaled=False, head_scale=None):
+    """Attention probabilities as a tensor, f32 [B, nheads, S, S] (slow path: VideoMAEEncoder(output_attentions=True), reference
+    utils/TAVFormer.py:362-375, :389), from q, k and the lse of attn_fwd.  head_scale: f32 [nheads] or [B, nheads] (head_mask) or None."""
+    probs = torch.empty(B, nheads, S, S, dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, q, q, B, S, nheads, key_mask, lse, None, mask_mode, scale, None, q_prescaled)
+    bstride = 0 if head_scale is None or head_scale.numel() == nheads else nheads
+    check(lib().tav_attn_probs(C.byref(a), ptr(probs), ptr(head_scale), bstride, stream()), "attn_probs")
+    return probs
+
+
+def head_scale(a, b, hs, c0, B, S, nheads, out=None):
+    """out[r, h*64+d] = (a or 0) + (c0 + hs[b, h]) * b[r, h*64+d] for token-major [B*S, nheads*64] tensors (row stride arbitrary); hs f32
+    [nheads] / [B, nheads] or None.  The head_mask arithmetic of the fusion encoder's slow path (reference utils/TAVFormer.py:368-370)."""
+    if out is None:
+        out = torch.empty(B * S, nheads * 64, dtype=b.dtype, device=b.device)
+    bstride = 0 if hs is None or hs.numel() == nheads else nheads
+    check(lib().tav_head_scale(ptr(a), ptr(b), ptr(out), dt(b), ptr(hs), bstride, float(c0), B, S, nheads,
+                               a.stride(-2) if a is not None else 0, b.stride(-2), out.stride(-2), stream()), "head_scale")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- layer norm
 def ln_fwd(x, gamma, beta, eps, *, want_f32=True, lp_dtype=None, act=0):
     """x [rows, W] f32 or bf16.  Returns (y_f32 | None, y_lp | None, mean, rstd)."""

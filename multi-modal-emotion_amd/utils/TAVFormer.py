@@ -73,8 +73,6 @@ class VideoMAEEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, output_attentions: bool = False, output_hidden_states: bool = False,
                 return_dict: bool = True):
-        if head_mask is not None or output_attentions:
-            raise NotImplementedError("head_mask / output_attentions are never used on the TAV path (reference tav_train.py) and are not built")
         if not hidden_states.is_cuda:
             raise RuntimeError("VideoMAEEncoder runs on libtavhip (GPU) only; there is no CPU fallback")
         ectx = runtime.ctx()
@@ -86,17 +84,38 @@ class VideoMAEEncoder(nn.Module):
         spec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode, branch="fusion")
         x = hidden_states.reshape(B * S, H)
         all_hidden = () if output_hidden_states else None
+        all_attn = [] if output_attentions else None
         for i, layer in enumerate(self.layer):
             if output_hidden_states:
                 all_hidden = all_hidden + (x.view(B, S, H),)
             x = runtime.cut_point("fusion", i, len(self.layer), x)
-            x, _ = E.encoder_layer(ectx, spec, x, None, key_mask, layer.params())
+            lspec = spec
+            if head_mask is not None or output_attentions:
+                # slow path (reference utils/TAVFormer.py:190, :368-370, :389): a per-head factor on the probabilities before the mask is
+                # added, and the probabilities themselves as a (detached) f32 tensor.  The training loop never asks for either.
+                lspec = E.LayerSpec(B, S, self.num_heads, self.eps, pre_ln=True, mask_mode=mode, branch="fusion",
+                                    head_scale=self._head_scale(head_mask[i], B) if head_mask is not None and head_mask[i] is not None else None,
+                                    probs_out=all_attn)
+            x, _ = E.encoder_layer(ectx, lspec, x, None, key_mask, layer.params())
         out = x.view(B, S, H)
         if output_hidden_states:
             all_hidden = all_hidden + (out,)
         if not return_dict:
-            return tuple(v for v in [out, all_hidden] if v is not None)
+            return tuple(v for v in [out, all_hidden, tuple(all_attn) if all_attn is not None else None] if v is not None)
         return out
+
+    def _head_scale(self, layer_head_mask, B):
+        """The layer's head_mask entry as per-head factors: anything that broadcasts over queries and keys -- a scalar, [heads],
+        [1, heads, 1, 1] or [B, heads, 1, 1] (what HF's get_head_mask produces) -> f32 [heads] or [B, heads]."""
+        m = torch.as_tensor(layer_head_mask, dtype=torch.float32, device=next(self.parameters()).device)
+        nh = self.num_heads
+        if m.numel() == 1:
+            return m.reshape(1).expand(nh).contiguous()
+        if m.numel() == nh and (m.dim() == 1 or tuple(m.shape[-3:]) == (nh, 1, 1)):
+            return m.reshape(nh).contiguous()
+        if m.numel() == B * nh and tuple(m.shape[-3:]) == (nh, 1, 1):
+            return m.reshape(B, nh).contiguous()
+        raise NotImplementedError(f"head_mask of shape {tuple(m.shape)}: only per-head (optionally per-batch-entry) factors are built")
 
 
 class MultiHeadAttention(nn.Module):

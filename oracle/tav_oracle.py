@@ -83,8 +83,10 @@ def _merge_heads(x):
 
 
 # ------------------------------------------------------------------------------------------------ fusion encoder
-def fusion_layer(sd, p, x, attention_mask, nh, eps):
-    """One VideoMAELayer of the reference's own copy (utils/TAVFormer.py:243-271 -> :343-391)."""
+def fusion_layer(sd, p, x, attention_mask, nh, eps, head_mask=None, probs_out=None):
+    """One VideoMAELayer of the reference's own copy (utils/TAVFormer.py:243-271 -> :343-391).
+    head_mask: the layer's entry of VideoMAEEncoder.forward(head_mask=) (:190), multiplied into the probabilities BEFORE the mask is
+    added (:368-370); probs_out: list that receives the returned attention_probs (:389, output_attentions=True)."""
     h = _ln(sd, p + ".layernorm_before", x, eps)                                     # :254
     a = p + ".attention.attention"
     q_bias, v_bias = sd.get(a + ".q_bias"), sd.get(a + ".v_bias")
@@ -94,8 +96,12 @@ def fusion_layer(sd, p, x, attention_mask, nh, eps):
     q, k, v = _split_heads(q, nh), _split_heads(k, nh), _split_heads(v, nh)
     scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])          # :357-359
     probs = torch.softmax(scores, dim=-1)                                            # :362 (dropout p=0 :366)
+    if head_mask is not None:                                                        # :368-370
+        probs = probs * head_mask
     if attention_mask is not None:                                                   # :372-375  mask added AFTER softmax
         probs = probs + attention_mask.expand(-1, 1, attention_mask.shape[-1], -1)
+    if probs_out is not None:
+        probs_out.append(probs)                                                      # :389
     ctx = _merge_heads(torch.matmul(probs, v))                                       # :383-387
     attn_out = _lin(sd, p + ".attention.output.dense", ctx)                          # :419 (dropout p=0)
     x = attn_out + x                                                                 # :260
@@ -104,9 +110,10 @@ def fusion_layer(sd, p, x, attention_mask, nh, eps):
     return _lin(sd, p + ".output.dense", h2) + x                                     # :432-437
 
 
-def fusion_encoder(sd, p, x, attention_mask, cfg):
+def fusion_encoder(sd, p, x, attention_mask, cfg, head_mask=None, probs_out=None):
     for i in range(cfg["layers"]):
-        x = fusion_layer(sd, f"{p}.layer.{i}", x, attention_mask, cfg["heads"], cfg["eps"])
+        x = fusion_layer(sd, f"{p}.layer.{i}", x, attention_mask, cfg["heads"], cfg["eps"],
+                         head_mask[i] if head_mask is not None else None, probs_out)  # :190
     return x                                                                         # plain tensor, :223
 
 

@@ -79,6 +79,42 @@ def test_fusion_encoder_golden_fp32(gpu, S, mname):
     assert rel(enc.layer[0].intermediate.dense.weight.grad[:8, :8], GOLD[f"fusion_S{S}_{mname}_dW1_l0"]) < 1e-3
 
 
+@pytest.mark.parametrize("mname,policy,tol", [("none", "fp32", 1e-4), ("masked", "fp32", 1e-4), ("masked", "bf16", 2e-2)])
+def test_fusion_encoder_head_mask_and_attentions(gpu, mname, policy, tol):
+    """VideoMAEEncoder.forward(head_mask=, output_attentions=True, output_hidden_states=True, return_dict=False) -- reference
+    utils/TAVFormer.py:171-223, :368-375, :389 -- against the oracle's restatement: output, hidden states, the returned probabilities
+    (head factor applied before the post-softmax mask) and the gradients through the head-masked context."""
+    runtime.set_precision(policy)
+    cfg = dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12)
+    enc = cf.fill_module_(VideoMAEEncoder(cfg, 2)).cuda()
+    B, S = 2, 37
+    x = (cf.tensor_for("fusion_hm_x", (B, S, 768), kind="bias") * 20).cuda().requires_grad_(True)
+    m = None
+    if mname == "masked":
+        m = torch.zeros(B, 1, 1, S)
+        m[..., : S // 4] = -0.03
+        m[1, ..., S // 2:] = 0.02
+    g = torch.Generator().manual_seed(3)
+    hm = torch.rand(2, 1, 12, 1, 1, generator=g) * 1.5              # HF get_head_mask layout: [layers, 1, heads, 1, 1]
+    hm[0, 0, 3] = 0.0                                               # a pruned head
+    out, hidden, attn = enc(x, None if m is None else m.cuda(), head_mask=hm.cuda(), output_attentions=True, output_hidden_states=True, return_dict=False)
+    out.square().mean().backward()
+    sd = {k: v.detach().cpu().float() for k, v in enc.state_dict().items()}
+    x_ref = x.detach().cpu().float().requires_grad_(True)
+    probs = []
+    y_ref = O.fusion_encoder({"e." + k: v.requires_grad_(True) for k, v in sd.items()}, "e", x_ref, m, dict(layers=2, heads=12, eps=1e-12), head_mask=hm, probs_out=probs)
+    y_ref.square().mean().backward()
+    assert rel(out, y_ref) < tol
+    assert len(hidden) == 3 and rel(hidden[0], x) == 0.0 and rel(hidden[2], out) == 0.0
+    assert len(attn) == 2 and attn[0].shape == (B, 12, S, S)
+    for a, pr in zip(attn, probs):
+        assert rel(a, pr) < (tol if policy == "fp32" else 5e-2)     # exponentials of bf16 dot products of 20x-scaled inputs
+    assert float(attn[0][:, 3].abs().max()) <= (0.03 if m is not None else 0.0) + 1e-6      # the pruned head returns the mask alone
+    assert rel(x.grad, x_ref.grad) < 10 * tol
+    with pytest.raises(NotImplementedError):
+        enc(x, None, head_mask=[torch.ones(1, 12, S, S), None])     # per-query / per-key head masks are not built
+
+
 @pytest.mark.parametrize("preset", ["A", "B"])
 def test_encoder_goldens_fp32(gpu, preset):
     """The three encoders on their own against what the HF modules the reference calls produced (closed-form weights, fp32 policy):
