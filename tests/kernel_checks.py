@@ -191,6 +191,8 @@ def check_gemm_tn_grouped_big(M=5000, flags=1):
         refs.append((a.float().t() @ b.float(), a.float().sum(0)))
     rs = []
     for nsplit in (1, 2, 3):
+        if (nsplit - 1) * (((M + nsplit - 1) // nsplit + 63) // 64 * 64) >= M:       # (the library refuses a split that would be empty)
+            continue
         outs = ops.gemm_tn_grouped(pairs, want_bias=True, flags=flags | (nsplit << 8))
         again = ops.gemm_tn_grouped(pairs, want_bias=True, flags=flags | (nsplit << 8))
         for k, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
@@ -548,10 +550,16 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=700, N=768, K=64, tile_m=16, out_f32=True))
             out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=16))
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
+            # ... and every length of its 3 + 2 image ring's prologue / tail: 1, 2, 3 and 5 K-tiles
+            for kk in (128, 192, 320):
+                out.append(lambda d=dtype, k=kk: check_gemm_nt(d, M=300, N=260, K=k, tile_m=16))
         if dtype == torch.bfloat16:
             out.append(check_gemm_nt_mixed_schedule)
         if dtype == torch.bfloat16:
             out.append(check_gemm_tn_grouped_big)
+            # the weight-gradient tile's ring with one, two and three K-tiles per split (the last one ragged)
+            out.append(lambda: check_gemm_tn_grouped_big(M=130))
+            out.append(lambda: check_gemm_tn_grouped_big(M=64))
         out.append(lambda d=dtype: check_gemm_nt_gelu_bwd(d))
         out.append(lambda d=dtype: check_gemm_nt_gelu_derivative_pair(d))
         if dtype == torch.bfloat16:
