@@ -577,6 +577,209 @@ __global__ __launch_bounds__(256, (fwd_nq<T, MODE, PRE>() > 2 ? 2 : TAV_ATT_FWD_
     }
 }
 
+// ================================================================================================= forward, 32x32x16 MFMA shape
+// The same algorithm as attn_fwd_kernel<bf16, 0, true> (no mask, pre-scaled q, lazy reference exponent, LDS-DMA ring) on
+// v_mfma_f32_32x32x16_bf16: a wave owns 32 queries x 64 keys per tile in 16 MFMA issues instead of 36, every lane's 32 scores of a tile belong to
+// ONE query (the running maximum needs one cross-lane step instead of two, the row sum none inside the loop), and the reference exponent is
+// one 16-register C operand.  The kernel is bound by instructions issued per SIMD (profiles/r03_experiments.md): fewer, longer MFMAs.
+//   S^T tile  (keys x queries) = K[32 keys][16 d] . Q^T[16 d][32 q]   lane (q = l % 32, h = l / 32): acc r <-> key 8 (r / 4) + 4 h + r % 4
+//   O^T tile  (d x queries)   += V^T[32 d][16 keys] . P^T[16 keys][32 q]; the k-slots of a 16-key chunk C are the keys the lane's accumulators
+//             8 c' .. 8 c' + 7 hold (16 C + 4 h + {0..3}, 16 C + 8 + 4 h + {0..3}) -- any assignment works as long as V^T's fragments use the same;
+//             M-tile T covers d in {16 T .. 16 T + 15} u {32 + 16 T .. 47 + 16 T}: two chunk pairs whose XOR-swizzled positions never share a
+//             32-byte bank window inside the 4-row block a transposed read fetches (HD<bf16>::row_off).
+// MEASURED SLOWER than the 16x16x32 kernel (video shape, batch 32: 254.6-263 us against 246.5-249 us; profiles/r03_experiments.md section 14)
+// and therefore not compiled by default: -DTAV_ATT_FWD32=1 builds it and routes the unmasked pre-scaled bf16 forward through it (all kernel
+// checks pass on it).
+#ifndef TAV_ATT_FWD32
+#define TAV_ATT_FWD32 0
+#endif
+#if TAV_ATT_FWD32
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+TAV_DEV void mma32(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+#ifndef TAV_ATT_FWD32_OCC
+#define TAV_ATT_FWD32_OCC 3
+#endif
+__global__ __launch_bounds__(256, TAV_ATT_FWD32_OCC) void attn_fwd32_kernel(const AttnP p) {
+    using T = bf16;
+    using H = HD<T>;
+    constexpr int BKV = 64;
+    constexpr int KROW_B = BKV * H::ROWB, VNAT_B = BKV * H::ROWB;
+    constexpr int BUF_B = KROW_B + VNAT_B + 2 * BKV * 4;       // (the layout of attn_fwd_kernel: K image, V image, per-key terms)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long hoff = (long)head * 64 * 2;
+    const char* Qb = p.q + (long)b * S * p.ld_q * 2 + hoff;
+    const char* Kb = p.k + (long)b * S * p.ld_k * 2 + hoff;
+    const char* Vb = p.v + (long)b * S * p.ld_v * 2 + hoff;
+
+    uint4 qf[4];                                              // Q[q][16 s + 8 h .. + 7]
+    {
+        int r = q0 + lq; r = r < S ? r : S - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(Qb + (long)r * p.ld_q * 2 + (2 * s + h) * 16);
+    }
+    // lane constants of the LDS reads; key rows / chunks of 16 keys / the ring slot are immediates or one scalar add away
+    unsigned koff[4], vtoff[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { koff[s] = (unsigned)H::row_off(lq, 2 * s + h); asm volatile("" : "+v"(koff[s])); }
+    {
+        const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int d0 = ((g & 1) ? 32 : 0) + 16 * tt;
+            vtoff[tt] = (unsigned)(H::row_off(4 * h + q4, d0 / 8 + (pp >> 1)) + 8 * (pp & 1));
+            asm volatile("" : "+v"(vtoff[tt]));
+        }
+    }
+    float m_run = -1e30f;
+    f32x16 mneg, oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mneg[r] = 0.f; oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    f32x2_t l2 = {0.f, 0.f};                                  // this lane's share of sum_key p (its 32 keys per tile); halves joined at the end
+
+    const int nkt = (S + BKV - 1) / BKV;
+    PairDma kv;
+    kv.init(Kb, Vb, p.ld_k * 2, p.ld_v * 2, S, smem, smem + KROW_B, tid);
+    auto dma = [&](int t, int buf, auto ragged_tag) __attribute__((always_inline)) {
+        kv.template issue<decltype(ragged_tag)::value != 0>(t, (unsigned)(buf * BUF_B));
+    };
+    auto store_kadd = [&](int t, int buf) {                   // -inf for the keys past S of the (ragged) last tile
+        if (tid < BKV) reinterpret_cast<float*>(smem + buf * BUF_B + KROW_B + VNAT_B)[tid] = (t * BKV + tid < S) ? 0.f : -INFINITY;
+    };
+    using TagNo = std::integral_constant<int, 0>;
+    using TagYes = std::integral_constant<int, 1>;
+    if (nkt == 1) { dma(0, 0, TagYes{}); store_kadd(0, 0); } else dma(0, 0, TagNo{});
+#pragma unroll
+    for (int s = 0; s < 4; ++s) settle(qf[s]);
+    wait_vmcnt0();
+    __syncthreads();
+
+    // One K/V tile.  LAST (compile time): the tile adds the per-key terms (-inf past S).  NEXT: 0 no prefetch, 1 regular, 2 ragged tile.
+    auto tile_body = [&](const int t, auto last_tag, auto next_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value != 0;
+        constexpr int NEXT = decltype(next_tag)::value;
+        const int cur = t & 1, nxt = cur ^ 1;
+        if constexpr (NEXT != 0) dma(t + 1, nxt, std::integral_constant<int, NEXT == 2>{});
+        const char* Krow = smem + cur * BUF_B;
+        const char* Vimg = Krow + KROW_B;
+        f32x16 sacc[2];
+        uint4 kf[2][4], vf[4][2];
+        // all eight K fragments are requested before the first MFMA, all sixteen V^T fragments behind the QK^T MFMAs: they land under the
+        // softmax arithmetic (a read issued right in front of the MFMA that needs it exposes the LDS latency sixteen times per tile)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) kf[kt][s] = *reinterpret_cast<const uint4*>(Krow + koff[s] + kt * 32 * H::ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                if (s == 0) sacc[kt] = mneg;
+                mma32(kf[kt][s], qf[s], sacc[kt]);
+            }
+#pragma unroll
+        for (int C = 0; C < 4; ++C)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const char* vt = Vimg + vtoff[tt] + C * 16 * H::ROWB;
+                const uint2 lo = lds_read_tr16(vt), hi = lds_read_tr16(vt + 8 * H::ROWB);
+                vf[C][tt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LAST) {
+            const float* kadd = reinterpret_cast<const float*>(Vimg + VNAT_B);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 ka = *reinterpret_cast<const f32x4*>(kadd + 32 * kt + 8 * j + 4 * h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][4 * j + r] += ka[r];
+                }
+        }
+        // sacc = s - m_ref.  Tile maximum of the lane's query over its 32 keys, then the other half's; the reference moves only when the
+        // maximum passes it by more than THR (or on the first tile, where it is still undefined: mneg = 0, sacc are the raw logits).
+        const bool first = (t == 0);
+        float m0 = vmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) m0 = vmax3(m0, sacc[0][r], sacc[0][r + 1]);
+        m0 = vmax3(m0, sacc[0][15], sacc[1][0]);
+#pragma unroll
+        for (int r = 1; r + 1 < 16; r += 2) m0 = vmax3(m0, sacc[1][r], sacc[1][r + 1]);
+        m0 = __builtin_elementwise_maximum(m0, sacc[1][15]);
+        {
+            const unsigned u = __float_as_uint(m0);
+            auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            m0 = vmax_raw(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+        }
+        if (__any(first || m0 > TAV_ATT_LAZY_THR)) {            // rare after the first tile: move the reference, THEN take the common path
+            const float shift = first ? m0 : fmaxf(m0, 0.f);
+            m_run = first ? shift : m_run + shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mneg[r] = -m_run; sacc[0][r] -= shift; sacc[1][r] -= shift; }
+            if (!first) {
+                const float al = fast_exp2(-shift);
+                l2 *= al;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= al; oacc[1][r] *= al; }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = fast_exp2(sacc[kt][r]);
+        {
+            f32x2_t la = {0.f, 0.f}, lb = {0.f, 0.f};            // (two chains: sixteen dependent packed adds are a latency chain of their own)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { la += f32x2_t{sacc[0][r], sacc[0][r + 1]}; lb += f32x2_t{sacc[1][r], sacc[1][r + 1]}; }
+            l2 += la + lb;
+        }
+        // O^T += V^T P^T, 16 keys per MFMA: chunk C = 2 kt + c' takes the accumulators 8 c' .. 8 c' + 7 of key tile kt
+#pragma unroll
+        for (int C = 0; C < 4; ++C) {
+            const int kt = C >> 1, c8 = 8 * (C & 1);
+            const uint4 pb = make_uint4(pack_bf16x2(sacc[kt][c8 + 0], sacc[kt][c8 + 1]), pack_bf16x2(sacc[kt][c8 + 2], sacc[kt][c8 + 3]),
+                                        pack_bf16x2(sacc[kt][c8 + 4], sacc[kt][c8 + 5]), pack_bf16x2(sacc[kt][c8 + 6], sacc[kt][c8 + 7]));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) mma32(vf[C][tt], pb, oacc[tt]);
+        }
+        if constexpr (NEXT == 2) store_kadd(t + 1, nxt);
+        wait_vmcnt0();                                        // tile t+1 has landed
+        __syncthreads();
+    };
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile_body(t, TagNo{}, std::integral_constant<int, 1>{});
+    if (t + 1 < nkt) { tile_body(t, TagNo{}, std::integral_constant<int, 2>{}); ++t; }
+    tile_body(t, TagYes{}, std::integral_constant<int, 0>{});
+
+    float l = l2[0] + l2[1];
+    {
+        const unsigned u = __float_as_uint(l);
+        auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        l = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+    }
+    const int q = q0 + lq;
+    if (q < S) {
+        const float inv = 1.f / l;
+        T* orow = reinterpret_cast<T*>(p.o) + ((long)b * S + q) * p.ld_o + head * 64;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                     // accumulator rows 8 j + 4 h + {0..3} of M-tile tt
+                const int d = (j < 2 ? 8 * j : 32 + 8 * (j - 2)) + 4 * h + 16 * tt;
+                st4(orow + d, f32x4{oacc[tt][4 * j], oacc[tt][4 * j + 1], oacc[tt][4 * j + 2], oacc[tt][4 * j + 3]} * inv);
+            }
+        if (h == 0) p.lse[((long)b * p.nh + head) * S + q] = (m_run + log2f(l)) * 0.6931471805599453f;
+    }
+}
+
+#endif   // TAV_ATT_FWD32
+
 // ================================================================================================= backward: dK, dV
 // query-tile height of the dK/dV kernel: 64 for bf16 (half as many barriers and staging round trips per MFMA as 32), 32 for
 // f32 (register budget)
@@ -1145,6 +1348,12 @@ static AttnP pack(const tav_attn_args* a) {
 }
 
 template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, hipStream_t st) {
+#if TAV_ATT_FWD32
+    if constexpr (sizeof(T) == 2 && MODE == 0 && PRE) {
+        hipLaunchKernelGGL(attn_fwd32_kernel, dim3((p.S + 127) / 128, p.nh, p.B), dim3(256), fwd_lds<bf16>(), st, p);
+        return (int)hipGetLastError();
+    }
+#endif
     constexpr int QW = 64 * fwd_nq<T, MODE, PRE>();          // queries per workgroup
     dim3 grid((p.S + QW - 1) / QW, p.nh, p.B);
     hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, PRE>), grid, dim3(256), fwd_lds<T>(), st, p);
