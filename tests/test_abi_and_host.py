@@ -484,3 +484,32 @@ def test_emitted_isa_discipline():
     bad_vmem = good.replace("\ts_nop 4\n", "\ts_nop 1\n")                                            # VMEM reads the SGPR 2 wait states later
     for txt in (bad_m0, bad_user, bad_lane, bad_vmem):
         assert ci.check_text([("bad", txt)])[0], txt
+
+
+def test_head_mask_layouts_and_oracle_head_mask():
+    """VideoMAEEncoder's head_mask entry (reference utils/TAVFormer.py:190, :368-370): the layouts HF's get_head_mask produces become per-head
+    factors, anything finer is refused; the oracle's restatement multiplies the probabilities before the post-softmax mask is added."""
+    from tav_amd.utils.TAVFormer import VideoMAEEncoder
+    enc = VideoMAEEncoder(dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12), 1)
+    h = torch.arange(12, dtype=torch.float32) / 11.0
+    assert torch.equal(enc._head_scale(h, 3), h)
+    assert torch.equal(enc._head_scale(h.view(1, 12, 1, 1), 3), h)
+    hb = torch.rand(3, 12, 1, 1)
+    assert torch.equal(enc._head_scale(hb, 3), hb.view(3, 12))
+    assert torch.equal(enc._head_scale(torch.tensor(0.5), 3), torch.full((12,), 0.5))
+    with pytest.raises(NotImplementedError):
+        enc._head_scale(torch.ones(1, 12, 5, 5), 3)
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 4, 768), None, head_mask=[h], output_attentions=True)      # no GPU: the module refuses, there is no CPU path
+    # oracle: probs * head_mask, THEN + mask; a zeroed head returns the mask alone
+    sd = {"e." + k: v for k, v in enc.state_dict().items()}
+    x = torch.randn(2, 5, 768)
+    m = torch.zeros(2, 1, 1, 5)
+    m[..., :2] = -0.25
+    hm = torch.ones(1, 1, 12, 1, 1)
+    hm[0, 0, 3] = 0.0
+    probs = []
+    y = O.fusion_encoder(sd, "e", x, m, dict(layers=1, heads=12, eps=1e-12), head_mask=hm, probs_out=probs)
+    assert y.shape == x.shape and probs[0].shape == (2, 12, 5, 5)
+    assert torch.allclose(probs[0][:, 3], m.expand(2, 1, 5, 5)[:, 0])
+    assert torch.allclose(probs[0][:, 0].sum(-1), torch.full((2, 5), 1.0 - 0.5), atol=1e-5)
