@@ -46,7 +46,26 @@ struct AttnP {
     long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     float scale;
     int pre;       // q holds q * scale * log2(e) already (the QKV projection's q rows were scaled in the weight copy)
+    int tiles;     // workgroups per (batch, head) slice of THIS launch (query tiles: forward, dQ; key tiles: dK/dV); grid = tiles * nh * B, 1-D
 };
+
+// Which tile of which (batch, head) slice a workgroup owns.  The grid is one-dimensional and walked through xcd_remap with the tile index
+// fastest: every XCD gets a contiguous band of whole (batch, head) slices, so all the tiles that stream one slice's K / V (forward, dQ)
+// or Q / dO (dK/dV) run on the SAME XCD, back to back, and share them through that XCD's L2.  With the plain (tiles, nh, B) grid the 12
+// tiles of a slice were dealt round-robin over the 8 XCDs and every L2 fetched every slice (round-3 PMC at the video shape: 1310 MB moved
+// per forward launch against 288 MB algorithmic).  Resident set per XCD at S = 1464: 32 CUs x 3 workgroups / 12 tiles = 8 slices x 375 KB
+// of K + V = 3 MB of the 4 MiB L2.  Placement is a speed matter only (the dispatcher's round-robin is observed, not promised).
+#ifndef TAV_ATT_XCD
+#define TAV_ATT_XCD 1      // 0: tiles dealt in plain id order (rounds 1-3), kept for A/B builds
+#endif
+struct AttnTile { int x, head, b; };
+TAV_DEV AttnTile attn_tile(const AttnP& p) {
+    const int id = TAV_ATT_XCD ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int hb = id / p.tiles, b = hb / p.nh;
+    AttnTile w;                    // (pinned to SGPRs: the slice bases feed the scalar operand of the LDS-DMA asm)
+    w.x = to_sgpr(id - hb * p.tiles); w.head = to_sgpr(hb - b * p.nh); w.b = to_sgpr(b);
+    return w;
+}
 
 TAV_DEV float vmax3(float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 // v_exp_f32 directly (exp2f() adds denormal-range fix-up code; scores are <= 0 after the max subtraction, flush is fine)
@@ -262,8 +281,9 @@ __global__ __launch_bounds__(256, (fwd_nq<T, MODE, PRE>() > 2 ? 2 : TAV_ATT_FWD_
     float* red = reinterpret_cast<float*>(smem + NBUF * BUF_B);   // [4][64] + [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
-    const int q0 = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+    const AttnTile wg = attn_tile(p);
+    const int head = wg.head, b = wg.b, S = p.S;
+    const int q0 = wg.x * (64 * NQ) + wave * (16 * NQ);
     const long hoff = (long)head * 64 * ES;
     const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
     const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256, (fwd_nq<T, MODE, PRE>() > 2 ? 2 : TAV_ATT_FWD_
         if (tid < 64) {
             const float c = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
             red[256 + tid] = c;
-            if (blockIdx.x == 0) p.corr[((long)b * p.nh + head) * 64 + tid] = c;
+            if (wg.x == 0) p.corr[((long)b * p.nh + head) * 64 + tid] = c;
         }
         __syncthreads();
     }
@@ -609,8 +629,9 @@ __global__ __launch_bounds__(256, TAV_ATT_FWD32_OCC) void attn_fwd32_kernel(cons
     constexpr int BUF_B = KROW_B + VNAT_B + 2 * BKV * 4;       // (the layout of attn_fwd_kernel: K image, V image, per-key terms)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const AttnTile wg = attn_tile(p);
+    const int head = wg.head, b = wg.b, S = p.S;
+    const int q0 = wg.x * 128 + wave * 32;
     const long hoff = (long)head * 64 * 2;
     const char* Qb = p.q + (long)b * S * p.ld_q * 2 + hoff;
     const char* Kb = p.k + (long)b * S * p.ld_k * 2 + hoff;
@@ -805,8 +826,9 @@ __global__ __launch_bounds__(256, (dkdv_fast32<T, MODE, PRE>() ? 3 : TAV_ATT_DKD
     float* red = reinterpret_cast<float*>(smem + 2 * BUF_B);   // [4][64] + [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const AttnTile wg = attn_tile(p);
+    const int head = wg.head, b = wg.b, S = p.S;
+    const int k0 = wg.x * 128 + wave * 32;
     const long hoff = (long)head * 64 * ES;
     const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
     const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
@@ -1057,8 +1079,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? TAV_ATT_DQ_OCC : 1)) void at
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-    const int head = blockIdx.y, b = blockIdx.z, S = p.S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const AttnTile wg = attn_tile(p);
+    const int head = wg.head, b = wg.b, S = p.S;
+    const int q0 = wg.x * 128 + wave * 32;
     const long hoff = (long)head * 64 * ES;
     const char* Qb = p.q + (long)b * S * p.ld_q * ES + hoff;
     const char* Kb = p.k + (long)b * S * p.ld_k * ES + hoff;
@@ -1314,6 +1337,7 @@ __global__ void head_scale_kernel(const T* __restrict__ a, const T* __restrict__
 static int check(const tav_attn_args* a, bool bwd) {
     if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse) return TAV_ERR_NULL;
     if (a->B <= 0 || a->S <= 0 || a->nheads <= 0) return TAV_ERR_SHAPE;
+    if (((a->S + 63) / 64) * a->nheads * a->B >= (1ll << 31)) return TAV_ERR_SHAPE;      // the grid is one-dimensional (attn_tile)
     if (a->dtype != TAV_BF16 && a->dtype != TAV_F32) return TAV_ERR_DTYPE;
     if (a->mask_mode < 0 || a->mask_mode > 2) return TAV_ERR_SHAPE;
     if (a->mask_mode != 0 && !a->key_mask) return TAV_ERR_NULL;
@@ -1344,26 +1368,29 @@ static AttnP pack(const tav_attn_args* a) {
     p.ld_dq = a->ld_dq; p.ld_dk = a->ld_dk; p.ld_dv = a->ld_dv;
     p.scale = a->scale;
     p.pre = a->q_prescaled != 0;
+    p.tiles = 1;
     return p;
 }
 
 template <typename T, int MODE, bool PRE> static int launch_fwd(const AttnP& p, hipStream_t st) {
 #if TAV_ATT_FWD32
     if constexpr (sizeof(T) == 2 && MODE == 0 && PRE) {
-        hipLaunchKernelGGL(attn_fwd32_kernel, dim3((p.S + 127) / 128, p.nh, p.B), dim3(256), fwd_lds<bf16>(), st, p);
+        AttnP pl = p; pl.tiles = (p.S + 127) / 128;
+        hipLaunchKernelGGL(attn_fwd32_kernel, dim3((unsigned)pl.tiles * p.nh * p.B), dim3(256), fwd_lds<bf16>(), st, pl);
         return (int)hipGetLastError();
     }
 #endif
     constexpr int QW = 64 * fwd_nq<T, MODE, PRE>();          // queries per workgroup
-    dim3 grid((p.S + QW - 1) / QW, p.nh, p.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, PRE>), grid, dim3(256), fwd_lds<T>(), st, p);
+    AttnP pl = p; pl.tiles = (p.S + QW - 1) / QW;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, PRE>), dim3((unsigned)pl.tiles * p.nh * p.B), dim3(256), fwd_lds<T>(), st, pl);
     return (int)hipGetLastError();
 }
 template <typename T, int MODE, bool PRE> static int launch_bwd(const AttnP& p, hipStream_t st) {
-    dim3 grid((p.S + 127) / 128, p.nh, p.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, p);        // also writes delta [B][nh][S]
+    AttnP pl = p; pl.tiles = (p.S + 127) / 128;
+    const dim3 grid((unsigned)pl.tiles * p.nh * p.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, PRE>), grid, dim3(256), dq_lds<T>(), st, pl);        // also writes delta [B][nh][S]
     constexpr size_t lds_dkdv = dkdv_lds<T, MODE, PRE>();
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), lds_dkdv, st, p);    // reads it
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, MODE, PRE>), grid, dim3(256), lds_dkdv, st, pl);    // reads it
     return (int)hipGetLastError();
 }
 template <typename T, bool PRE> static int dispatch_fwd(const AttnP& p, int mode, hipStream_t st) {

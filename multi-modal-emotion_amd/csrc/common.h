@@ -158,6 +158,14 @@ TAV_DEV unsigned lds_addr(const void* p) {
 // reads it" (1 wait state; the v_mov that feeds %1 is often the instruction right in front) and "VALU writes SGPR -> VALU reads it
 // (2) / VMEM reads it (5)" behind.  Without them the lane read returns the register's PREVIOUS value.
 TAV_DEV int to_sgpr(int v) { int s; asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(s) : "v"(v)); return s; }
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.
+// Give each XCD a contiguous band of tiles (bijective for any grid size); the caller decodes the band index so that
+// neighbouring tiles of one XCD reuse the same operand panel (GEMM: the A rows; attention: the K / V of one (batch, head)).
+TAV_DEV int xcd_remap(int id, int total) {
+    const int q = total >> 3, r = total & 7, x = id & 7, k = id >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
 TAV_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"

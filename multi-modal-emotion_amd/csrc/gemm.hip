@@ -38,15 +38,6 @@ struct GemmNT {
 
 TAV_DEV int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so ids congruent mod 8 share an L2.
-// Give each XCD a contiguous band of tiles (bijective for any grid size), and walk n fastest inside the band so
-// neighbouring tiles of one XCD reuse the same A rows.
-TAV_DEV int xcd_remap(int id, int total) {
-    const int q = total >> 3, r = total & 7, x = id & 7, k = id >> 3;
-    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + k;
-}
-
 // ablation switches for tools/ab_build.sh (timing experiments only; results are wrong with any of them set)
 #ifdef TAV_ABL_NOMFMA
 #define TAV_NT_MMA(b, a, c) do { (c)[0] += __uint_as_float((b).x ^ (a).x); } while (0)

@@ -589,6 +589,9 @@ def all_checks():
         out.append(lambda d=dtype: check_attention(d, 0, B=2, S=1, nh=2, pre=True))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=3136, nh=1, pre=True))
         out.append(lambda d=dtype: check_attention(d, 0, B=2, S=1464, nh=2, pre=True))
+        # odd slice / tile counts: the one-dimensional XCD-banded grid (attn_tile) must stay a bijection when tiles * heads * batch % 8 != 0
+        out.append(lambda d=dtype: check_attention(d, 0, B=3, S=300, nh=5, pre=True))
+        out.append(lambda d=dtype: check_attention(d, 2, B=3, S=135, nh=3))
         out.append(lambda d=dtype: check_attention(d, 2, B=2, S=481, nh=12, ref_style_mask=True, pre=True))
         out.append(lambda d=dtype: check_attention(d, 0, B=2, S=328, nh=2, pre=True, spike=6.0))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=328, nh=2, pre=True, spike=300.0))
