@@ -330,7 +330,7 @@ def main():
             engine.bump_weight_epoch()                       # the operand casts must be part of the captured step
             stepper.opt.zero_grad()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=work_stream):
+            with runtime.capture(graph, work_stream):
                 static_loss = one_step()
         except Exception as e:
             capture_failed(e)
@@ -369,7 +369,7 @@ def main():
         def graphed(fn):
             stepper.opt.zero_grad()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=work_stream):
+            with runtime.capture(g, work_stream):
                 out = fn()
             return lambda: (g.replay(), out)[1]
 
@@ -424,7 +424,7 @@ def main():
                 engine.bump_weight_epoch()
                 step_a.opt.zero_grad()
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=work_stream):
+                with runtime.capture(ga, work_stream):
                     loss_a = stepA()
                 ga.replay()
                 el, _, _ = timed(lambda: (ga.replay(), loss_a)[1], args.steps)
@@ -486,8 +486,9 @@ def main():
         except Exception:
             pass
         # the other kernel families, timed in the same instrumented pass (HIP event pair per launch, each launch alone on the device):
-        # attention (forward 4 B h S^2 d, backward 10 B h S^2 d algorithmic FLOPs: the backward EXECUTES 14 -- it recomputes S and dP in both of
-        # its kernels to stay free of atomics), the weight-gradient GEMMs (2 tokens N1 N2) and the LayerNorm kernels (HBM-bound: bytes read + written once)
+        # attention (forward 4 B h S^2 d, backward 8 B h S^2 d algorithmic FLOPs -- the contract's fwd + bwd = 3 x fwd; the backward EXECUTES 14, it
+        # recomputes S and dP in both of its kernels to stay free of atomics: `frac_executed`), the weight-gradient GEMMs (2 tokens N1 N2) and the
+        # LayerNorm kernels (HBM-bound: bytes read + written once)
         fams = {}
         for name, d in getattr(ops.profile_stop, "families", {}).items():
             if name == "gemm_nt" or not d["launches"]:
@@ -501,6 +502,9 @@ def main():
                 fams[{"attn": "attention", "gemm_tn": "gemm_tn"}[name]] = {
                     "kernel": {"attn": "tav::attn_fwd_kernel / attn_bwd_dq_kernel / attn_bwd_dkdv_kernel", "gemm_tn": "tav::gemm_tn_grouped_big_kernel / gemm_tn_grouped_kernel / gemm_tn_kernel"}[name],
                     "bound": "mfma", "achieved": round(a_, 2), "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a_ / MFMA_PEAK_BF16_TFLOPS, 4)}
+                if name == "attn":
+                    fams["attention"]["frac_executed"] = round(d["work_exec"] / max(d["secs"], 1e-9) / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4)
+                    fams["attention"]["flops_convention"] = "algorithmic 4 (fwd) + 8 (bwd) B h S^2 d = 12 per layer; executed 4 + 14"
             f_ = fams["layernorm" if name == "ln" else {"attn": "attention", "gemm_tn": "gemm_tn"}[name]]
             f_.update({"launches_per_step": d["launches"] // 2, "avg_launch_us": round(d["secs"] / d["launches"] * 1e6, 2), "serial_ms_per_step": round(d["secs"] / 2 * 1e3, 3),
                        "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"])})

@@ -14,6 +14,11 @@ import torch
 import torch.distributed as dist
 
 
+
+def _rt():
+    from . import runtime          # (lazy: runtime imports engine, which imports this module's users)
+    return runtime
+
 class BucketedAllReduce:
     def __init__(self, params, bucket_mb=48.0, process_group=None, reduce_dtype=None, single_rank_ok=False):
         self.params = [p for p in params if p.requires_grad]
@@ -90,7 +95,7 @@ class BucketedAllReduce:
             # the bucket's gradients were produced on several streams (buckets follow the ready order and span branches): the
             # reducer stream waits for the tail of EVERY one of them, not only of the stream that completed the bucket
             for st in self._streams.pop(i, set()) | {torch.cuda.current_stream()}:
-                self.side.wait_stream(st)
+                _rt().stream_wait(self.side, st)
             ctx = torch.cuda.stream(self.side)
         else:
             import contextlib
@@ -160,7 +165,7 @@ class BucketedAllReduce:
         self._complete = set()
         self._next = 0
         if self._cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            _rt().stream_wait(torch.cuda.current_stream(), self.side)
 
     # ---- graph mode: no hooks, no side stream.  The backward (captured in one hipGraph) ends with pack_all(); the collectives are
     # issued eagerly between that graph and the optimizer graph (no RCCL call is ever captured); see bench.py.
@@ -316,7 +321,7 @@ class GraphedStep:
         g0 = torch.cuda.CUDAGraph()
         runtime.begin_cuts(self.fractions)
         runtime.begin_layer_groups()
-        with torch.cuda.graph(g0, stream=stream, **mode):
+        with runtime.capture(g0, stream, **mode):
             self.loss = forward_loss()
             self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
             self.groups = runtime.end_layer_groups()
@@ -324,11 +329,11 @@ class GraphedStep:
         self.graphs.append(g0)
         for s in range(1, self.seg.nseg):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, pool=g0.pool(), **mode):
+            with runtime.capture(g, stream, pool=g0.pool(), **mode):
                 self._run_and_pack(s)
             self.graphs.append(g)
         self.gu = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gu, stream=stream, pool=g0.pool(), **mode):
+        with runtime.capture(self.gu, stream, pool=g0.pool(), **mode):
             stepper.update()
         self._adopt_buckets()
 
@@ -448,10 +453,10 @@ class GraphedStep:
         main = torch.cuda.current_stream()
         for g, (_, flat) in zip(self.graphs, self.flats):
             g.replay()
-            self.side.wait_stream(main)                  # bucket s is packed: ship it while the next graph runs
+            _rt().stream_wait(self.side, main)                  # bucket s is packed: ship it while the next graph runs
             with torch.cuda.stream(self.side):
                 self._reduce(flat)
-        main.wait_stream(self.side)
+        _rt().stream_wait(main, self.side)
         self.gu.replay()
         return self.loss
 
@@ -471,13 +476,13 @@ class GraphedStep:
             self._run_and_pack(s)
             flat = self.flats[s][1]
             if cuda:
-                self.side.wait_stream(torch.cuda.current_stream())
+                _rt().stream_wait(self.side, torch.cuda.current_stream())
                 with torch.cuda.stream(self.side):
                     self._reduce(flat)
             else:
                 self._reduce(flat)
         if cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            _rt().stream_wait(torch.cuda.current_stream(), self.side)
         sig = self.bucket_signature()
         if self._plan is None:
             self._plan = sig

@@ -257,8 +257,19 @@ def _arena_into(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2):
     from . import runtime as _rt
     if not _rt.grad_slots:
         return None
-    g = lambda p: _rt.grad_slots.get(p.data_ptr()) if p is not None else None       # noqa: E731
-    return [(g(w2), g(b2)), (g(w1), g(b1)), (g(wo), g(bo)), (_rt.fused_slot((wq, wk, wv)), _rt.fused_slot((bq, bk, bv)) if (bq is not None and bk is not None and bv is not None) else None)]
+    # Every slot is handed out ONCE (popped): a layer differentiated a second time inside the same segment (shared / re-applied layer) gets no
+    # slot, its launch writes a fresh buffer and autograd ADDS that to the gradient already sitting in the arena view -- a second launch into
+    # the same slot would overwrite the first gradient and then be added to itself (2 x the second gradient, silently).
+    g = lambda p: _rt.grad_slots.pop(p.data_ptr(), None) if p is not None else None       # noqa: E731
+
+    def fused(ps):
+        if any(p is None for p in ps):
+            return None
+        v = _rt.fused_slot(ps)
+        for p in ps:                                 # (also when they are not adjacent: a partly used triple must not be half-taken later)
+            _rt.grad_slots.pop(p.data_ptr(), None)
+        return v
+    return [(g(w2), g(b2)), (g(w1), g(b1)), (g(wo), g(bo)), (fused((wq, wk, wv)), fused((bq, bk, bv)))]
 
 
 class EncoderLayerFn(torch.autograd.Function):

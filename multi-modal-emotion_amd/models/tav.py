@@ -133,10 +133,10 @@ class PreFormer(nn.Module):
             runtime.share_with(s_a, audio_features, audio_mask)
             runtime.share_with(s_v, video_embeds, visual_mask)
             with torch.cuda.stream(s_a):
-                s_a.wait_event(ev)
+                runtime.stream_wait(s_a, main, ev)
                 x_audio = audio_frontend()
             with torch.cuda.stream(s_v):
-                s_v.wait_event(ev)
+                runtime.stream_wait(s_v, main, ev)
                 x_video, Nv = video_frontend()
         if input_ids is not None:
             input_ids = input_ids.to(dev)
@@ -145,7 +145,7 @@ class PreFormer(nn.Module):
             parts.append(x_text)
         if side:
             for st, ten in ((s_a, x_audio), (s_v, x_video)):
-                main.wait_stream(st)
+                runtime.stream_wait(main, st)
                 ten.record_stream(main)
         else:
             x_audio = audio_frontend()
@@ -245,13 +245,13 @@ class TAVForMAE(nn.Module):
             runtime.share_with(s_vid, video_embeds, visual_mask)
             runtime.share_with(s_txt, input_ids, text_attention_mask)
             with torch.cuda.stream(s_vid):
-                s_vid.wait_event(ev)
+                runtime.stream_wait(s_vid, main, ev)           # (ev was recorded on the caller's stream: here, or by PreFormer.forward)
                 vid, Sv = video_branch()
             with torch.cuda.stream(s_aud):
-                s_aud.wait_event(ev)
+                runtime.stream_wait(s_aud, main, ev)
                 aud, Sa = audio_branch()
             with torch.cuda.stream(s_txt):
-                s_txt.wait_event(ev)
+                runtime.stream_wait(s_txt, main, ev)
                 _, t = self.bert(input_ids, text_attention_mask)                         # :485
         else:
             aud, Sa = audio_branch()
@@ -261,7 +261,7 @@ class TAVForMAE(nn.Module):
         av = self.random_mae_encoder(av.view(B, Sf, 768), attention_mask.to(dev))       # :487 (fusion branch stays on the caller's stream)
         if runtime.multistream[0]:
             for st, ten in ((s_aud, aud), (s_vid, vid), (s_txt, t)):
-                main.wait_stream(st)
+                runtime.stream_wait(main, st)
                 ten.record_stream(main)
         p_drop = self.dropout_p if check == "train" else 0.0
         self._drop_calls += 1

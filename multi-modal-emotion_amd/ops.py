@@ -36,15 +36,16 @@ def profile_start(kinds):
     _prof = {"kinds": {kinds} if isinstance(kinds, str) else set(kinds), "ev": []}
 
 
-def _prof_launch(family, select, work, nbytes, launch):
+def _prof_launch(family, select, work, nbytes, launch, work_exec=None):
     """Run `launch()`; while a profile of `family` is active, bracket it with a HIP event pair on the launch stream and record its
-    algorithmic work (FLOPs for the MFMA-bound families, 0 for the HBM-bound one) and algorithmic bytes."""
+    algorithmic work (FLOPs for the MFMA-bound families, 0 for the HBM-bound one) and algorithmic bytes.  work_exec: the FLOPs the kernels
+    really execute where that differs from the algorithmic count (the atomic-free attention backward recomputes two products)."""
     if _prof is not None and family in _prof["kinds"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        _prof["ev"].append((e0, e1, float(work), select, float(nbytes), family))
+        _prof["ev"].append((e0, e1, float(work), select, float(nbytes), family, float(work if work_exec is None else work_exec)))
     else:
         launch()
 
@@ -56,9 +57,10 @@ def profile_stop(select="bf16"):
     torch.cuda.synchronize()
     allev, _prof = _prof["ev"], None
     fam = {}
-    for e0, e1, work, sel, nbytes, family in allev:
-        d = fam.setdefault(family, {"work": 0.0, "bytes": 0.0, "secs": 0.0, "launches": 0})
+    for e0, e1, work, sel, nbytes, family, work_exec in allev:
+        d = fam.setdefault(family, {"work": 0.0, "work_exec": 0.0, "bytes": 0.0, "secs": 0.0, "launches": 0})
         d["work"] += work
+        d["work_exec"] += work_exec
         d["bytes"] += nbytes
         d["secs"] += e0.elapsed_time(e1) * 1e-3
         d["launches"] += 1
@@ -280,8 +282,10 @@ def attn_bwd(q, k, v, o, dout, lse, corr, B, S, nheads, *, key_mask=None, mask_m
     a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
     a.ld_do, a.ld_dq, a.ld_dk, a.ld_dv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
     es = q.element_size()
-    _prof_launch("attn", "bf16" if q.dtype == torch.bfloat16 else "f32", 10.0 * B * nheads * S * S * 64, 8 * B * S * H * es,     # Q, K, V, O, dO in; dQ, dK, dV out
-                 lambda: check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd"))
+    # algorithmic work by the contract (BASELINE.md section 2 / SURVEY.md section 8d: fwd + bwd = 3 x fwd, so the backward is 2 x 4 B h S^2 d); the two
+    # atomic-free kernels EXECUTE 14 B h S^2 d (S and dP are recomputed in both), reported beside it as `frac_executed`
+    _prof_launch("attn", "bf16" if q.dtype == torch.bfloat16 else "f32", 8.0 * B * nheads * S * S * 64, 8 * B * S * H * es,     # Q, K, V, O, dO in; dQ, dK, dV out
+                 lambda: check(lib().tav_attn_bwd(C.byref(a), stream()), "attn_bwd"), work_exec=14.0 * B * nheads * S * S * 64)
     return dqkv
 
 

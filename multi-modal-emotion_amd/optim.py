@@ -73,8 +73,14 @@ class FusedAdamW:
         self._lr_host = None
 
     def zero_grad(self, set_to_none=True):
+        """set_to_none=True (torch >= 2.0 default): drop the gradients, the next step() skips those parameters.  set_to_none=False (the default of
+        the torch 1.10 the reference pins, README_and_Requirements/requirements.txt:100): keep the tensors and fill them with zeros -- a later
+        step() then still decays the weights and applies the momentum (see train_model.tav_train.grad_accum)."""
         for p in self.params:
-            p.grad = None
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
 
     def _active(self):
         return [p for p in self.params if p.grad is not None]

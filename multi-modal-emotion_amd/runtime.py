@@ -43,6 +43,7 @@ def branch_streams(n=3):
     if dev not in _streams:
         pr = [0, -1, 0] if _prio else [0, 0, 0]
         _streams[dev] = [torch.cuda.Stream(device=dev, priority=pr[i]) for i in range(n)]
+    _register_branches(_streams[dev])
     return _streams[dev]
 
 
@@ -54,7 +55,102 @@ def front_streams(n=2):
     dev = torch.cuda.current_device()
     if dev not in _front:
         _front[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    _register_branches(_front[dev])
     return _front[dev]
+
+
+# ---- capture guard.  Round 3 lost a run to a core dump (`hipStreamEndCapture` inside torch/cuda/graphs.py capture_end, ROCm 7.2): while a
+# stream capture is in progress, a dependency edge between a BRANCH stream and any stream other than the capture's ORIGIN -- branch to
+# branch, or to a stream the capture never forked -- builds a graph the runtime crashes on when the capture ends.  The legal topology is a
+# star: a branch forks from the origin (waits for an event recorded there) and is joined by the origin (origin waits for the branch).
+# Every cross-stream dependency of this package goes through stream_wait(); captures go through capture(); while one is active an illegal
+# edge raises RuntimeError naming the two streams instead of producing that graph.  Pure host logic (stream identity only): tested on the CPU.
+_capture = None          # {"origin": stream, "branches": [streams handed out or forked while the capture is active]}
+
+
+def _same(a, b):
+    return a is b or a == b
+
+
+def _register_branches(streams):
+    if _capture is not None:
+        for st in streams:
+            if not _same(st, _capture["origin"]) and not any(_same(st, b) for b in _capture["branches"]):
+                _capture["branches"].append(st)
+
+
+def capture_active():
+    return _capture is not None
+
+
+def check_edge(waiter, producer):
+    """Raise if `waiter` waiting for `producer` is an edge the capture in progress cannot hold (no-op outside a capture)."""
+    if _capture is None or _same(waiter, producer):
+        return
+    origin, branches = _capture["origin"], _capture["branches"]
+
+    def known(st):
+        return _same(st, origin) or any(_same(st, b) for b in branches)
+    for st in (waiter, producer):
+        if not known(st):
+            raise RuntimeError(f"hipGraph capture on {origin}: stream {st} is neither the capture's origin nor one of its registered branches "
+                               f"(runtime.branch_streams / front_streams / fork); a dependency on it ({waiter} waits for {producer}) would crash hipStreamEndCapture")
+    if not _same(waiter, origin) and not _same(producer, origin):
+        raise RuntimeError(f"hipGraph capture on {origin}: dependency between two branch streams ({waiter} waits for {producer}); under capture every "
+                           f"edge must start or end at the origin stream (ROCm 7.2 crashes in hipStreamEndCapture otherwise) -- join through the origin")
+
+
+def stream_wait(waiter, producer, event=None):
+    """`waiter` waits for everything `producer` has been given so far (or for `event`, which was recorded on `producer`).  The one place
+    cross-stream dependencies are made, so the capture guard sees them all."""
+    check_edge(waiter, producer)
+    if event is not None:
+        waiter.wait_event(event)
+    else:
+        waiter.wait_stream(producer)
+
+
+class capture:
+    """`with runtime.capture(graph, stream, **kw):` = torch.cuda.graph(graph, stream=stream, **kw) with the guard above armed: `stream` is the
+    origin; streams handed out by branch_streams() / front_streams() inside the block (or passed as `branches=`) are its branches."""
+
+    def __init__(self, graph, stream, branches=(), **kw):
+        import torch
+        self._cm = torch.cuda.graph(graph, stream=stream, **kw)
+        self._origin, self._branches = stream, list(branches)
+
+    def __enter__(self):
+        global _capture
+        if _capture is not None:
+            raise RuntimeError("runtime.capture: a capture is already in progress in this process")
+        _capture = {"origin": self._origin, "branches": list(self._branches)}
+        try:
+            return self._cm.__enter__()
+        except BaseException:
+            _capture = None
+            raise
+
+    def __exit__(self, *exc):
+        global _capture
+        try:
+            return self._cm.__exit__(*exc)
+        finally:
+            _capture = None
+
+
+class guard_only:
+    """The guard without a hipGraph (CPU tests of the logic; `origin` / branches are any objects with identity)."""
+
+    def __init__(self, origin, branches=()):
+        self._origin, self._branches = origin, list(branches)
+
+    def __enter__(self):
+        global _capture
+        _capture = {"origin": self._origin, "branches": list(self._branches)}
+
+    def __exit__(self, *exc):
+        global _capture
+        _capture = None
 
 
 def share_with(stream, *tensors):

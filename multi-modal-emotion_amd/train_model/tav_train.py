@@ -75,8 +75,11 @@ def get_statistics(input, label, model, PREFormer, criterion, Metric, check="tra
 class TrainStep:
     """One optimisation step of reference :56-65: get_statistics -> backward -> (all-reduce) -> clip_grad_norm_ -> AdamW."""
 
-    def __init__(self, model, PREFormer, criterion, lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=48.0, reduce_dtype=None):
+    def __init__(self, model, PREFormer, criterion, lr=1e-6, weight_decay=1e-4, clip=1.0, bucket_mb=48.0, reduce_dtype=None, zero_grad_like_torch_1_10=False):
         self.model, self.pre, self.criterion, self.clip = model, PREFormer, criterion, clip
+        # what `model.zero_grad()` (reference :64-65, :98-99, :104-105) does to .grad: torch 1.10 -- the version the reference pins,
+        # requirements.txt:100 -- zero-FILLS; torch >= 2.0 sets None.  Matters only for grad_accum's second step (see there).
+        self.zero_to_none = not zero_grad_like_torch_1_10
         self.params = [p for p in model.parameters() if p.requires_grad] + [p for p in PREFormer.parameters() if p.requires_grad]
         self.opt = FusedAdamW(self.params, lr=lr, weight_decay=weight_decay)
         self.reducer = None
@@ -94,9 +97,9 @@ class TrainStep:
             self.reducer.finish()
         return loss
 
-    def update(self):
-        norm = self.opt.clip_and_step(self.clip)
-        self.opt.zero_grad()
+    def update(self, clip=True):
+        norm = self.opt.clip_and_step(self.clip if clip else None)
+        self.opt.zero_grad(set_to_none=self.zero_to_none)
         return norm
 
     def __call__(self, input, label, check="train", epoch=0, n_visual_true=None):
@@ -153,8 +156,15 @@ def not_grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, cr
 def grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criterion, stepper, scheduler, patience, Metric, prev_val_loss, log_val, path=None):
     """reference :87-119, the dialogue-level variant used on epochs with epoch % epoch_switch != 0.  Kept with its quirk: the loss is
     divided by the dialogue length (`dataset.retGradAccum(i)` -> (accum_iter, accum_sum)) but the optimizer still steps -- and the
-    gradients are zeroed -- after EVERY batch (:96-100), so the extra step at a dialogue end (:102-106) runs on zeroed gradients:
-    torch's AdamW skips parameters whose .grad is None, hence that second step changes nothing but the scheduler call."""
+    gradients are zeroed -- after EVERY batch (:96-100), so the extra, unclipped `optimizer.step()` at a dialogue end (:102-106) runs on zeroed
+    gradients.  What that step does depends on the torch version behind `model.zero_grad()`:
+      * torch >= 2.0 (`set_to_none=True`): every .grad is None, AdamW skips every parameter -- nothing changes but the scheduler call
+        (the default here: `TrainStep(zero_grad_like_torch_1_10=False)`);
+      * torch 1.10, the version the reference pins (README_and_Requirements/requirements.txt:100; `set_to_none=False`): the gradients are
+        zero TENSORS, so AdamW still runs -- weights decay by (1 - lr * wd), both moments shrink by their betas, the step counter advances and
+        the parameters move along the remaining momentum (`TrainStep(zero_grad_like_torch_1_10=True)` /
+        `train_tav_network(..., zero_grad_like_torch_1_10=True)`).
+    Both readings are tested (tests/test_abi_and_host.py on the call sequence, tests/test_model_gpu.py against torch.optim.AdamW)."""
     iters = len(train_dataloader)
     total_loss_train = 0.0
     for batch_idx, (train_input, train_label) in enumerate(train_dataloader):
@@ -167,7 +177,7 @@ def grad_accum(epoch, train_dataloader, val_dataloader, model, PREFormer, criter
         stepper.update()
         scheduler.step(epoch + batch_idx / iters)
         if ((batch_idx + 1) % accum_sum == 0) or (batch_idx + 1 == iters):
-            stepper.update()                     # no gradients left: a no-op, as in the reference
+            stepper.update(clip=False)           # reference :103: optimizer.step() without clip_grad_norm_; no-op or a momentum / decay step (docstring)
             scheduler.step(epoch + batch_idx / iters)
         if ((batch_idx + 1) % log_val == 0) or (batch_idx + 1 == iters):
             log(Metric, total_loss_train / iters, "train")
@@ -189,10 +199,10 @@ def one_epoch(epoch, train_dataloader, val_dataloader, model, PREFormer, criteri
 
 
 def train_tav_network(model, PREFormer, train_dataloader, val_dataloader, criterion, learning_rate, epochs, weight_decay, T_max, Metric, patience, clip,
-                      epoch_switch, checkpoint=None, path=None, log_val=2400):
+                      epoch_switch, checkpoint=None, path=None, log_val=2400, zero_grad_like_torch_1_10=False):
     """reference :147-164.  `path` (None = keep nothing on disk) replaces the cluster path hard-coded at :137; `checkpoint` is a loaded
     best.pt dict whose optimizer / scheduler state resumes the run (:152-155)."""
-    stepper = TrainStep(model, PREFormer, criterion, lr=learning_rate, weight_decay=weight_decay, clip=clip)
+    stepper = TrainStep(model, PREFormer, criterion, lr=learning_rate, weight_decay=weight_decay, clip=clip, zero_grad_like_torch_1_10=zero_grad_like_torch_1_10)
     scheduler = CosineWarmRestarts(stepper.opt, T_0=T_max)
     prev_val_loss = 100
     if checkpoint is not None:

@@ -361,6 +361,26 @@ def tavformae_forward(sd, cfg, input_ids, text_attention_mask, audio_features, v
     return _lin(sd, "linear1", tav)                                                                   # :499
 
 
+def randomize_model_(model):
+    """M1, models/tav.py:442 + :461-471: `VideoMAEEncoder(...).apply(self.randomize_model)`.  `apply` visits every sub-module (children
+    first) and the rule itself walks `named_modules()` of what it is handed, so a Linear nested d levels deep is redrawn d + 1 times; the
+    LAST draw (the call on the root) is the one that stays.  Restated with the same traversal so that, from one RNG state, the resulting
+    weights equal the reference's bit for bit (pinned by oracle/validate_vs_reference.py against the reference's own function body):
+    xavier_uniform on every Linear / Embedding weight, Linear bias 0, LayerNorm weight := ones(768) (a fresh Parameter, :467), bias 0;
+    q_bias / v_bias are not touched (they stay 0 from utils/TAVFormer.py:330-331)."""
+    def rule(sub):
+        for _, m in sub.named_modules():
+            if isinstance(m, (torch.nn.Linear, torch.nn.Embedding)):
+                torch.nn.init.xavier_uniform_(m.weight)
+            elif isinstance(m, torch.nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight = torch.nn.Parameter(torch.ones(768))
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+        return sub
+    return model.apply(rule)
+
+
 def new_cross_entropy(logits, target, epoch, epoch_switch, class_weights):
     """utils/global_functions.py:69-83."""
     if epoch % epoch_switch == 0:

@@ -7,6 +7,12 @@
 2. Composes those modules exactly as models/tav.py:344-417 and :473-504 read (models/tav.py itself cannot be imported:
    it needs pytorchvideo/torchvision/torchaudio and fetches a processor at import time) and writes the
    expected outputs to tests/golden/*.npz.  Fixtures hold outputs only; weights and inputs are closed-form.
+3. (round 4) The composition is no longer pinned by a transcription alone: `reference_methods()` parses /root/reference/models/tav.py
+   as TEXT at run time (`ast`), takes the reference's OWN function bodies -- `PreFormer.forward`, its three helpers, `TAVForMAE.forward`
+   and `TAVForMAE.randomize_model` -- compiles them in a namespace that holds only what those bodies name (torch, nn, HF's
+   `_compute_mask_indices`) and binds them to the Ref* objects below.  Nothing of the reference is written into this repository; the
+   module's import-time side (missing packages, the processor fetch at :172) is never executed.  The executed bodies must agree
+   BIT FOR BIT with the transcribed forwards (which stay as the readable statement of what is pinned), and the fixtures are taken from them.
 
 Usage:  python oracle/validate_vs_reference.py [--write]
 """
@@ -29,6 +35,44 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+REF_TAV_PY = "/root/reference/models/tav.py"
+REF_METHODS = {"PreFormer": ("forward", "_mask_hidden_states", "_get_feat_extract_output_lengths", "_get_feature_vector_attention_mask"),
+               "TAVForMAE": ("forward", "randomize_model")}
+
+
+def reference_methods():
+    """{(class, method): function} compiled from the reference's own source text (see the module docstring, item 3)."""
+    import ast
+    from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+    with open(REF_TAV_PY) as f:
+        tree = ast.parse(f.read(), filename=REF_TAV_PY)
+    fns, where = {}, {}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in REF_METHODS:
+            picked = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in REF_METHODS[node.name]]
+            missing = set(REF_METHODS[node.name]) - {n.name for n in picked}
+            if missing:
+                raise RuntimeError(f"{REF_TAV_PY}: class {node.name} has no {sorted(missing)}")
+            ns = {"torch": torch, "nn": torch.nn, "np": np, "_compute_mask_indices": _compute_mask_indices}
+            mod = ast.Module(body=picked, type_ignores=[])        # line numbers stay the reference's: tracebacks cite models/tav.py:NNN
+            exec(compile(mod, REF_TAV_PY, "exec"), ns)
+            for n in picked:
+                fns[(node.name, n.name)] = ns[n.name]
+                where[(node.name, n.name)] = (n.lineno, n.end_lineno)
+    return fns, where
+
+
+def bind_reference(obj, cls_name, fns):
+    """A shallow copy of a Ref* module whose methods are the reference's own function bodies (parameters are shared with `obj`)."""
+    import copy
+    import types
+    twin = copy.copy(obj)
+    for (c, m), fn in fns.items():
+        if c == cls_name:
+            object.__setattr__(twin, m, types.MethodType(fn, twin))
+    return twin
 
 
 def hf_text(cfg):
@@ -68,6 +112,7 @@ class RefPreFormer(torch.nn.Module):
         self.masked_spec_embed = torch.nn.Parameter(torch.zeros(cfg["audio"]["hidden"]))
         self.videomae, _ = hf_video(cfg["video"])
         self.wav_2_768 = torch.nn.Linear(cfg["audio"]["hidden"], 768)
+        self.check_shapes = 2                      # (models/tav.py:267 starts at 1 and prints the three shapes once)
         cf.fill_module_(self)
 
     def forward(self, input_ids, audio_features, video_embeds, text_mask, audio_mask, visual_mask):
@@ -110,6 +155,7 @@ class RefTAVForMAE(torch.nn.Module):
         self.wav2vec2 = hf_audio(cfg["audio"])
         self.videomae, _ = hf_video(cfg["video"])
         self.wav_2_768_2 = torch.nn.Linear(cfg["audio"]["hidden"], 768)
+        self.dropout = torch.nn.Dropout(cfg.get("dropout", 0.5))          # models/tav.py:449, used only when check == "train"
         cf.fill_module_(self)
         self.eval()
 
@@ -224,6 +270,34 @@ def main():
         print(f"TransformerEncoder early_div={early}: rel err {e:.2e}")
         out[f"transformer_encoder_early{int(early)}_y"] = y_ref.detach().numpy()
 
+    # ---- the reference's own function bodies (text of models/tav.py, parsed here; the transcription is the fallback) -------------
+    ref_fns = ref_where = None
+    if os.path.exists(REF_TAV_PY):
+        ref_fns, ref_where = reference_methods()
+        print("reference bodies compiled from " + REF_TAV_PY + ": " + ", ".join(f"{c}.{m} :{a}-{b}" for (c, m), (a, b) in sorted(ref_where.items())))
+        # M1: TAVForMAE.randomize_model (:461-471) against the oracle's statement of the init rule, same RNG state
+        from transformers import VideoMAEConfig as _VC
+        from utils.TAVFormer import VideoMAEEncoder as _RefEnc
+
+        class _Holder:                      # randomize_model only uses `self` to be a method
+            pass
+        h = _Holder()
+        torch.manual_seed(77)
+        e_ref = _RefEnc(_VC(), 1)
+        st = torch.get_rng_state()
+        e_ref.apply(lambda mod: ref_fns[("TAVForMAE", "randomize_model")](h, mod))
+        torch.manual_seed(77)
+        e_or = _RefEnc(_VC(), 1)
+        torch.set_rng_state(st)
+        O.randomize_model_(e_or)
+        bad = [k for k, v in e_ref.state_dict().items() if not torch.equal(v, e_or.state_dict()[k])]
+        print(f"TAVForMAE.randomize_model (reference body) vs oracle init rule: {len(e_ref.state_dict())} tensors, {len(bad)} differ")
+        if bad:
+            print("INIT RULE NOT PINNED:", bad[:4])
+            sys.exit(1)
+    else:
+        print("NOTE: " + REF_TAV_PY + " not present -- composition pinned by the transcription only")
+
     # ---- 2. HF encoders vs oracle, 3. composed PreFormer / TAVForMAE, per preset ------------------------------------
     for name in ("A", "B"):
         cfg = tiny_cfg(name)
@@ -249,6 +323,23 @@ def main():
         params = [p for p in list(pre.parameters()) + list(model.parameters()) if p.requires_grad]
         tav, tav_embed, amask = pre(batch["input_ids"], batch["audio_features"], batch["video_embeds"], batch["text_mask"], batch["audio_mask"], batch["visual_mask"])
         logits = model(batch["input_ids"], batch["text_mask"], batch["audio_features"], batch["video_embeds"], batch["visual_mask"], tav, tav_embed, amask)
+        if ref_fns is not None:
+            # the reference's OWN bodies of PreFormer.forward (models/tav.py:344-417, through its helpers :269-342) and TAVForMAE.forward
+            # (:473-504), executed on the same modules: the transcription above must agree bit for bit, and the fixtures come from THESE
+            x_pre, x_model = bind_reference(pre, "PreFormer", ref_fns), bind_reference(model, "TAVForMAE", ref_fns)
+            tav_x, embed_x, amask_x = x_pre.forward(input_ids=batch["input_ids"], audio_features=batch["audio_features"], video_embeds=batch["video_embeds"],
+                                                    text_mask=batch["text_mask"], audio_mask=batch["audio_mask"], visual_mask=batch["visual_mask"],
+                                                    device="cpu", train=False)
+            logits_x = x_model.forward(batch["input_ids"], batch["text_mask"], batch["audio_features"], batch["video_embeds"], batch["visual_mask"],
+                                       tav_x, embed_x, amask_x, batch_size=2, check="val")
+            same = dict(tav=torch.equal(tav_x, tav), tav_embed=torch.equal(embed_x, tav_embed) and embed_x.dtype == tav_embed.dtype,
+                        attention_mask=torch.equal(amask_x, amask), logits=torch.equal(logits_x, logits))
+            print(f"preset {name} reference function bodies (models/tav.py:{ref_where[('PreFormer', 'forward')][0]}-{ref_where[('PreFormer', 'forward')][1]}, "
+                  f":{ref_where[('TAVForMAE', 'forward')][0]}-{ref_where[('TAVForMAE', 'forward')][1]}) vs transcription, bitwise: {same}")
+            if not all(same.values()):
+                print("TRANSCRIPTION DIFFERS FROM THE REFERENCE'S OWN FORWARD")
+                sys.exit(1)
+            tav, tav_embed, amask, logits = tav_x, embed_x, amask_x, logits_x
         loss = torch.nn.functional.cross_entropy(logits, labels)
         loss.backward()
         gn = grad_norm(params)

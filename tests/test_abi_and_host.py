@@ -179,6 +179,98 @@ def test_state_dict_keys_follow_reference_names():
     assert torch.all(L.layernorm_before.weight == 1) and torch.all(L.layernorm_before.bias == 0) and torch.all(L.output.dense.bias == 0)
 
 
+def test_randomize_model_matches_oracle_init_rule():
+    """M1 (reference models/tav.py:442, :461-471): from one RNG state the product's `.apply(randomize_model)` leaves the fusion stack with
+    exactly the weights the oracle's restatement of the rule gives (which oracle/validate_vs_reference.py pins, bit for bit, against the
+    reference's own function body): same traversal, so the same number of xavier draws per Linear, the last one staying."""
+    from tav_amd.utils.TAVFormer import VideoMAEEncoder
+    cfg = cfgmod.preset("B-tiny")
+    model = TAVForMAE(dict(output_dim=7, dropout=0.5, learn_PosEmbeddings=True, num_layers=12), cfg)
+    fcfg, nl = dict(cfg["fusion"]), cfg["fusion"]["layers"]
+    torch.manual_seed(5)
+    a = VideoMAEEncoder(fcfg, nl)
+    st = torch.get_rng_state()
+    a.apply(model.randomize_model)
+    torch.manual_seed(5)
+    b = VideoMAEEncoder(fcfg, nl)
+    torch.set_rng_state(st)
+    O.randomize_model_(b)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    w = sa["layer.0.intermediate.dense.weight"]
+    bound = math.sqrt(6.0 / (w.shape[0] + w.shape[1]))                       # xavier_uniform
+    assert w.abs().max() <= bound and w.abs().max() > 0.9 * bound
+
+
+def test_capture_guard_refuses_edges_that_crash_end_capture():
+    """runtime.check_edge / stream_wait: while a capture is active, a dependency whose two ends are both branch streams, or that touches a
+    stream the capture never registered, raises (round 3: such a graph dumped core in hipStreamEndCapture); fork / join through the
+    origin stays legal.  Host logic only -- the streams here are stand-ins with identity."""
+    from tav_amd import runtime
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name, self.waits = name, []
+
+        def __repr__(self):
+            return f"<stream {self.name}>"
+
+        def wait_stream(self, other):
+            self.waits.append(("stream", other))
+
+        def wait_event(self, ev):
+            self.waits.append(("event", ev))
+
+    origin, a, b, stray = FakeStream("origin"), FakeStream("audio"), FakeStream("video"), FakeStream("stray")
+    runtime.stream_wait(a, b)                                   # no capture: anything goes
+    assert not runtime.capture_active()
+    with runtime.guard_only(origin, branches=[a, b]):
+        assert runtime.capture_active()
+        runtime.stream_wait(a, origin, event="ev")              # fork: branch waits for an event recorded on the origin
+        runtime.stream_wait(origin, a)                          # join: origin waits for the branch
+        runtime.stream_wait(origin, origin)
+        with pytest.raises(RuntimeError, match="two branch streams.*audio.*video"):
+            runtime.stream_wait(a, b)
+        with pytest.raises(RuntimeError, match="stray.*neither the capture's origin nor one of its registered branches"):
+            runtime.stream_wait(stray, origin)
+        with pytest.raises(RuntimeError, match="stray"):
+            runtime.stream_wait(origin, stray, event="ev")
+        n_before = len(a.waits)
+        with pytest.raises(RuntimeError):
+            runtime.stream_wait(a, stray)
+        assert len(a.waits) == n_before                        # refused BEFORE the dependency is made
+    assert not runtime.capture_active()
+    assert a.waits[0] == ("stream", b) and ("event", "ev") in a.waits and origin.waits[0] == ("stream", a)
+
+
+def test_gradient_arena_slots_are_single_use():
+    """engine._arena_into: a layer differentiated twice within one data-parallel segment must not write its second weight gradient into the
+    arena slot the first one already owns (AccumulateGrad would then add the slot to itself); the second request gets no destinations."""
+    from tav_amd import engine, runtime
+    H, F = 4, 8
+    mk = lambda *s: torch.nn.Parameter(torch.zeros(*s))           # noqa: E731
+    wq, wk, wv, wo, w1, w2 = mk(H, H), mk(H, H), mk(H, H), mk(H, H), mk(F, H), mk(H, F)
+    bq, bk, bv, bo, b1, b2 = mk(H), mk(H), mk(H), mk(H), mk(F), mk(H)
+    order = [wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2]
+    flat = torch.zeros(sum(p.numel() for p in order))
+    off, views = 0, {}
+    for p in order:
+        views[p.data_ptr()] = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    runtime.grad_slots.clear()
+    runtime.grad_slots.update(views)
+    try:
+        first = engine._arena_into(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2)
+        assert all(d is not None for pair in first for d in pair)
+        assert first[3][0].shape == (3 * H, H) and first[3][0].data_ptr() == views[wq.data_ptr()].data_ptr()     # Wq | Wk | Wv as one fused destination
+        second = engine._arena_into(wq, wk, wv, bq, bk, bv, wo, bo, w1, b1, w2, b2)
+        assert second is None or all(d is None for pair in second for d in pair)
+    finally:
+        runtime.grad_slots.clear()
+
+
 def test_remap_reference_keys():
     sd = {"videomae.encoder.layer.0.attention.attention.q_bias": torch.ones(4), "videomae.encoder.layer.0.attention.attention.v_bias": torch.ones(4) * 2,
           "wav2vec2.encoder.pos_conv_embed.conv.weight_g": torch.ones(1, 1, 3), "wav2vec2.encoder.pos_conv_embed.conv.weight_v": torch.ones(2, 2, 3),
@@ -363,8 +455,8 @@ def test_grad_accum_loop_steps_like_the_reference(monkeypatch):
         reducer = None
         opt = None
 
-        def update(self):
-            calls.append(("update",))
+        def update(self, clip=True):
+            calls.append(("update",) if clip else ("update-unclipped",))
 
     class Sched:
         def step(self, e):
@@ -395,10 +487,24 @@ def test_grad_accum_loop_steps_like_the_reference(monkeypatch):
     seq = [c[0] for c in calls]
     # batch index 1 ends dialogue 1 (accum_sum = 2: (1+1) % 2 == 0), batch index 4 ends dialogue 2 ((4+1) % 5 == 0) and is the last one
     assert seq == ["backward", "update", "sched",
-                   "backward", "update", "sched", "update", "sched",
+                   "backward", "update", "sched", "update-unclipped", "sched",       # reference :102-106: optimizer.step() without clip_grad_norm_
                    "backward", "update", "sched",
                    "backward", "update", "sched",
-                   "backward", "update", "sched", "update", "sched"]
+                   "backward", "update", "sched", "update-unclipped", "sched"]
+
+
+def test_zero_grad_readings_torch_1_10_and_torch_2():
+    """FusedAdamW.zero_grad / TrainStep.zero_to_none: the reference's `model.zero_grad()` zero-FILLS under its pinned torch 1.10
+    (requirements.txt:100) and sets None under torch >= 2; both are offered, the default is the torch-2 reading."""
+    from tav_amd.optim import FusedAdamW
+    ps = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))]
+    opt = FusedAdamW(ps)
+    ps[0].grad = torch.full((3,), 2.0)
+    opt.zero_grad(set_to_none=False)
+    assert torch.equal(ps[0].grad, torch.zeros(3)) and ps[1].grad is None            # (a gradient that never existed stays None, as in torch)
+    assert [p for p in opt._active()] == [ps[0]]                                      # the zero tensor still takes part in the next step
+    opt.zero_grad()
+    assert ps[0].grad is None and opt._active() == []
 
 
 def test_collate_batch_device_contract():

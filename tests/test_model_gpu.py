@@ -229,6 +229,34 @@ def test_fused_adamw_matches_torch(gpu):
             assert rel(p, q) < 1e-5
 
 
+def test_grad_accum_second_step_under_both_zero_grad_readings(gpu):
+    """reference train_model/tav_train.py:96-106: step, zero_grad, then -- at a dialogue end -- a second unclipped optimizer.step().  Under torch 1.10
+    (the reference's pin) zero_grad zero-fills and that step decays the weights and moves them along the momentum; under torch >= 2 it is a no-op.
+    The fused optimizer reproduces torch.optim.AdamW in both readings."""
+    torch.manual_seed(0)
+    shapes = [(300, 64), (77,), (7, 128)]
+    for like_1_10 in (True, False):
+        ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        ref = torch.optim.AdamW(qs, lr=1e-2, weight_decay=1e-1)
+        opt = FusedAdamW(ps, lr=1e-2, weight_decay=1e-1)
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step()
+        ref.zero_grad(set_to_none=not like_1_10)
+        opt.clip_and_step(1.0)
+        opt.zero_grad(set_to_none=not like_1_10)
+        before = [p.detach().clone() for p in ps]
+        ref.step()                                   # the dialogue-end step: no clipping (:103)
+        opt.clip_and_step(None)
+        for p, q, b in zip(ps, qs, before):
+            assert rel(p, q) < 1e-5
+            moved = (p.detach() - b).abs().max().item()
+            assert (moved > 1e-4) if like_1_10 else (moved == 0.0)
+
+
 @pytest.mark.parametrize("policy,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
 def test_transformer_encoder_vs_oracle_and_golden(gpu, policy, tol):
     """Row T1 (alternative fusion stack): forward vs the golden made from the reference class, forward+backward vs the oracle."""
@@ -631,7 +659,7 @@ def test_specaugment_on_device_is_capturable(gpu):
         pre(train=True, **kw)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with runtime.capture(g, s):
             noisy, _, _ = pre(train=True, **kw)
         outs = []
         for _ in range(2):
@@ -690,7 +718,7 @@ def test_collate_device_feeds_captured_step(gpu):
         for p in list(pre.parameters()) + list(model.parameters()):
             p.grad = None
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with runtime.capture(graph, s):
             static_loss = step()
         inp2, lab2 = collate_batch_device(items(2, [7000, 8000]), "train", device="cuda", n_visual_true=4, generator=gen)
         for d, d2 in zip(inp, inp2):

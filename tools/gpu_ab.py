@@ -49,7 +49,7 @@ if "attn" in what:
             o, lse, aux = ops.attn_fwd(q, k, v, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre)
             do = rnd(B * S, H)
             lo, med = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, aux if mode == 2 else None, B, S, nh, key_mask=mask, mask_mode=mode, q_prescaled=pre))
-            print(f"[{tag}] attn_bwd pre{int(pre)} {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2.5 * fl / lo / 1e6:7.1f} TF")
+            print(f"[{tag}] attn_bwd pre{int(pre)} {name:7s} S={S:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2.0 * fl / lo / 1e6:7.1f} TF (8 B h S^2 d; executes 14)")
 if "gemm" in what:
     for (name, M, N, K) in [("video qkv", B * 1464, 2304, 768), ("video out", B * 1464, 768, 768), ("video ffn1", B * 1464, 3072, 768),
                             ("video ffn2", B * 1464, 768, 3072), ("fusion qkv", B * 481, 2304, 768), ("audio ffn1", B * 249, 3072, 768),
