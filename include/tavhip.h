@@ -28,7 +28,8 @@ enum {
     TAV_ERR_NULL = -1,  /* required pointer missing           */
     TAV_ERR_SHAPE = -2, /* size not supported by the kernel   */
     TAV_ERR_DTYPE = -3, /* dtype code / combination rejected  */
-    TAV_ERR_ALIGN = -4  /* stride or offset breaks 16-B access */
+    TAV_ERR_ALIGN = -4, /* stride or offset breaks 16-B access */
+    TAV_ERR_NO_RCCL = -5 /* v5: tav_comm_* / tav_allreduce_bucket called, but no librccl could be loaded (it is resolved lazily) */
 };
 
 int tav_version(void);                 /* ABI version, bumped on any signature change */
@@ -68,6 +69,7 @@ typedef struct tav_gemm_nt_args {
     float alpha;
     const float* a_dequant; /* in_dtype == TAV_FP8: device scalars (amax/448 of each operand, tav_fp8_amax) multiplied into alpha; NULL = 1 */
     const float* b_dequant;
+    int64_t gelu_zb;        /* v5: zb batch stride of gelu_in in elements when it differs from c_zb (0 = c_zb): the side input of a strided / padded output */
     int32_t tile_m_hint;    /* 0 = let the library choose (it may cover the rows with two launches: whole rounds of 256 x 256 tiles, then 128-wide tiles over the rest); bits 0-4: 2/3/4 = force 64/96/128 x 128 workgroup tiles (4 waves), 8 = 256 x 128, 16 = 256 x 256 (8 waves, bf16 operands), 17 = library's choice of ONE tile for all rows; bits 5-7: LDS ring depth 2-4 (tuning / tests) */
 } tav_gemm_nt_args;
 int tav_gemm_nt(const tav_gemm_nt_args* args, void* stream);
@@ -200,10 +202,21 @@ typedef struct tav_ln_args {
     int64_t ld_x, ld_y, ld_dy, ld_dx;
     float eps;
     int32_t act;            /* 1: y = gelu_erf(layernorm(x)) (wav2vec2 "layer" conv blocks, HF wav2vec2:275-301); bwd needs beta */
+    int32_t defer_param_reduce; /* v5, bwd: 1 = write the per-workgroup column sums to `partials` (required; dgamma / dbeta ignored) and do NOT
+                                   launch the second stage -- the caller reduces them later with tav_ln_param_reduce_multi */
 } tav_ln_args;
 int tav_ln_fwd(const tav_ln_args* args, void* stream);
 int tav_ln_bwd(const tav_ln_args* args, void* stream);
 int tav_ln_bwd_partials(int64_t rows);
+/* v5.  Second stage of up to TAV_LN_REDUCE_MAX deferred LayerNorm backwards in ONE launch (a training step has ~210 of them; nobody reads
+ * dgamma / dbeta before the optimizer): item i sums the `nblocks` = tav_ln_bwd_partials(rows) partial rows its tav_ln_bwd wrote, in the same
+ * fixed order as the immediate form (bitwise equal results).  `items` is a HOST array (copied into the kernel arguments). */
+#define TAV_LN_REDUCE_MAX 64
+typedef struct tav_ln_reduce_item {
+    const float* partials; float* dgamma; float* dbeta;
+    int32_t nblocks, W, accumulate, pad_;
+} tav_ln_reduce_item;
+int tav_ln_param_reduce_multi(const tav_ln_reduce_item* items, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels (all HBM-bound). */
@@ -218,8 +231,14 @@ int tav_cast_weight(const float* src, int64_t R, int64_t C, void* dst, int64_t l
  * (scale_n multiplies what is written to dst, NOT dst_t: the attention pre-scale of the q rows, tav_attn_args.q_prescaled)
  * handled by one launch (grid = blocks_per_tensor x n) -- all operand copies of a transformer layer at once. */
 int tav_cast_weights_multi(const void* descs, int32_t n, int32_t blocks_per_tensor, void* stream);
-/* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst) and its dgrad form [k*ci... see DESIGN.md] */
-int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dst_dtype, void* stream);
+/* Conv1d weight [co][ci][k] f32 -> GEMM operand [co][k][ci] (dst), its column-buffer dgrad form [k*ci][co] (dst_t) and (v5) the
+ * per-output-phase dgrad operands (dst_phase, conv_stride): for r = 0 .. conv_stride-1 the block ph_r[ci][q'*co + c] =
+ * W[c][ci][r + (Q_r-1-q')*conv_stride], Q_r = ceil((k-r)/conv_stride), blocks back to back (co*ci*k elements in all).  With them
+ * dx[s*m + r] is ONE NT GEMM per phase over Q_r consecutive dy rows (overlapping rows, lda = co) -- see engine.ConvGemmFn. */
+int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, void* dst_phase, int64_t conv_stride,
+                         int32_t dst_dtype, void* stream);
+/* v5: zero rows [0, pad) and [pad + T, T + 2*pad) of each of the B batch entries of a [B][T + 2*pad][C] buffer */
+int tav_zero_pad_rows(void* buf, int32_t dtype, int64_t B, int64_t T, int64_t C, int64_t pad, void* stream);
 /* generic strided cast/copy: dst[r][c] = src[r][c] for r<R, c<C (dtypes may differ) */
 int tav_cast2d(const void* src, int32_t src_dtype, int64_t ld_src, void* dst, int32_t dst_dtype, int64_t ld_dst, int64_t R, int64_t C,
                void* stream);
@@ -366,6 +385,7 @@ int tav_adamw_chunked(float* const* params, const float* const* grads, float* co
  * (in place, mean, f32 or bf16 elements); returns 1000 + ncclResult_t when RCCL refuses.  The reference has no distributed code; this
  * replaces what torch DistributedDataParallel would do around train_model/tav_train.py:59-62.  The Python host layer (ddp.py) issues the
  * same collective through torch.distributed's "nccl" backend, which IS RCCL on ROCm. */
+int tav_comm_rccl_version(int32_t* version);   /* v5: ncclGetVersion() of the RCCL that was loaded (resolved lazily with dlopen: libtavhip has no link-time dependency on it) */
 int tav_comm_unique_id(void* out128);
 int tav_comm_init_rank(void** comm, int32_t nranks, const void* unique_id128, int32_t rank);
 int tav_comm_destroy(void* comm);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
 TAV_F32, TAV_BF16, TAV_FP8 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -25,7 +25,7 @@ class GemmNTArgs(C.Structure):
                 ("nzb", i32), ("nzg", i32),
                 ("a_zb", i64), ("a_zg", i64), ("b_zb", i64), ("b_zg", i64), ("c_zb", i64), ("c_zg", i64), ("bias_zg", i64),
                 ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("alpha", f32),
-                ("a_dequant", vp), ("b_dequant", vp), ("tile_m_hint", i32)]
+                ("a_dequant", vp), ("b_dequant", vp), ("gelu_zb", i64), ("tile_m_hint", i32)]
 
 
 class GemmTNArgs(C.Structure):
@@ -52,7 +52,15 @@ class LnArgs(C.Structure):
                 ("mean", vp), ("rstd", vp),
                 ("dy", vp), ("dy_dtype", i32), ("dx_add", vp), ("dx_f32", vp), ("dx_lp", vp),
                 ("dgamma", vp), ("dbeta", vp), ("partials", vp), ("accumulate_params", i32),
-                ("rows", i64), ("W", i64), ("ld_x", i64), ("ld_y", i64), ("ld_dy", i64), ("ld_dx", i64), ("eps", f32), ("act", i32)]
+                ("rows", i64), ("W", i64), ("ld_x", i64), ("ld_y", i64), ("ld_dy", i64), ("ld_dx", i64), ("eps", f32), ("act", i32),
+                ("defer_param_reduce", i32)]
+
+
+class LnReduceItem(C.Structure):
+    _fields_ = [("partials", vp), ("dgamma", vp), ("dbeta", vp), ("nblocks", i32), ("W", i32), ("accumulate", i32), ("pad_", i32)]
+
+
+LN_REDUCE_MAX = 64
 
 
 class TextEmbedArgs(C.Structure):
@@ -76,6 +84,7 @@ _SIGS = {
     "tav_fp8_amax": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp]),
     "tav_fp8_quantize": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, i64, vp]),
     "tav_splitk_reduce": (C.c_int, [vp, vp, i32, i64, i32, vp]),
+    "tav_comm_rccl_version": (C.c_int, [C.POINTER(i32)]),
     "tav_comm_unique_id": (C.c_int, [vp]),
     "tav_comm_init_rank": (C.c_int, [C.POINTER(vp), i32, vp, i32]),
     "tav_comm_destroy": (C.c_int, [vp]),
@@ -87,9 +96,11 @@ _SIGS = {
     "tav_ln_fwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd": (C.c_int, [C.POINTER(LnArgs), vp]),
     "tav_ln_bwd_partials": (C.c_int, [i64]),
+    "tav_ln_param_reduce_multi": (C.c_int, [C.POINTER(LnReduceItem), i32, vp]),
     "tav_cast_weight": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i32, vp]),
     "tav_cast_weights_multi": (C.c_int, [vp, i32, i32, vp]),
-    "tav_cast_conv_weight": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, vp]),
+    "tav_cast_conv_weight": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, i64, i32, vp]),
+    "tav_zero_pad_rows": (C.c_int, [vp, i32, i64, i64, i64, i64, vp]),
     "tav_cast2d": (C.c_int, [vp, i32, i64, vp, i32, i64, i64, i64, vp]),
     "tav_transpose2d": (C.c_int, [vp, vp, i32, i64, i64, i64, vp]),
     "tav_add_f32": (C.c_int, [vp, vp, vp, vp, i32, i64, vp]),

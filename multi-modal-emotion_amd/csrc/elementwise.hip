@@ -85,8 +85,13 @@ __global__ void cast_weight_multi_kernel(const CastDesc* __restrict__ descs) {
 }
 
 // nn.Conv1d weight [co][ci][k] -> dst[co][k*CI + ci] (forward/wgrad operand) and dst_t[k*CI + ci][co] (dgrad operand)
+// ... and (v5) dst_ph: the input-gradient operands BY OUTPUT PHASE.  dx[s*m + r] = sum over the taps j = r + q*s of dy[m - q] . W[:, :, j]: for every
+// residue r of the input position, one NT GEMM whose A row is the Q_r = ceil((K - r) / s) CONSECUTIVE dy rows m - (Q_r - 1) .. m (overlapping
+// rows, lda = CO) and whose B operand is  ph_r[ci][q' * CO + co] = W[co][ci][r + (Q_r - 1 - q') * s]  -- the blocks ph_0 | ph_1 | ... stand
+// one after the other (CI * Q_r * CO elements each, CO * CI * K in all).  No [T_out, K * CI] column buffer and no col2im pass.
 template <typename TD>
-__global__ void cast_conv_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, TD* __restrict__ dst_t, int CO, int CI, int K) {
+__global__ void cast_conv_weight_kernel(const float* __restrict__ src, TD* __restrict__ dst, TD* __restrict__ dst_t, TD* __restrict__ dst_ph, int CO, int CI,
+                                        int K, int stride) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)CO * CI * K;
     if (idx >= n) return;
@@ -96,6 +101,13 @@ __global__ void cast_conv_weight_kernel(const float* __restrict__ src, TD* __res
     const float v = src[((long)co * CI + ci) * K + kk];
     if (dst) ET<TD>::st(dst + idx, v);
     if (dst_t) ET<TD>::st(dst_t + ((long)kk * CI + ci) * CO + co, v);
+    if (dst_ph) {
+        const int r = kk % stride, q = kk / stride;
+        long off = 0;                                       // elements of the phases before r
+        for (int rp = 0; rp < r; ++rp) off += (long)CI * CO * ((K - rp + stride - 1) / stride);
+        const int Q = (K - r + stride - 1) / stride;
+        ET<TD>::st(dst_ph + off + ((long)ci * Q + (Q - 1 - q)) * CO + co, v);
+    }
 }
 
 // dst[z][c][r] = src[z][r][c]  (batched 2-D transpose through a padded LDS tile; both sides coalesced)
@@ -624,6 +636,7 @@ extern "C" const char* tav_error_string(int code) {
         case TAV_ERR_SHAPE: return "unsupported shape";
         case TAV_ERR_DTYPE: return "unsupported dtype";
         case TAV_ERR_ALIGN: return "stride/offset not 16-byte aligned";
+        case TAV_ERR_NO_RCCL: return "RCCL not available (librccl could not be loaded)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown";
     }
 }
@@ -644,12 +657,36 @@ extern "C" int tav_cast_weights_multi(const void* descs_dev, int32_t n, int32_t 
     hipLaunchKernelGGL(cast_weight_multi_kernel, dim3(blocks_per_tensor, n), dim3(256), 0, ST, (const CastDesc*)descs_dev);
     return tav_last_error();
 }
-extern "C" int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, int32_t dt, void* stream) {
-    if (!src || (!dst && !dst_t)) return TAV_ERR_NULL;
+extern "C" int tav_cast_conv_weight(const float* src, int64_t co, int64_t ci, int64_t k, void* dst, void* dst_t, void* dst_phase, int64_t conv_stride,
+                                    int32_t dt, void* stream) {
+    if (!src || (!dst && !dst_t && !dst_phase)) return TAV_ERR_NULL;
     if (co <= 0 || ci <= 0 || k <= 0) return TAV_ERR_SHAPE;
+    if (dst_phase && (conv_stride <= 0 || conv_stride > k)) return TAV_ERR_SHAPE;     // (stride > k would leave phases without a tap)
     const long n = co * ci * k;
-    if (dt == TAV_BF16) hipLaunchKernelGGL((cast_conv_weight_kernel<bf16>), G1(n), src, (bf16*)dst, (bf16*)dst_t, (int)co, (int)ci, (int)k);
-    else if (dt == TAV_F32) hipLaunchKernelGGL((cast_conv_weight_kernel<float>), G1(n), src, (float*)dst, (float*)dst_t, (int)co, (int)ci, (int)k);
+    const int cs = dst_phase ? (int)conv_stride : 1;
+    if (dt == TAV_BF16) hipLaunchKernelGGL((cast_conv_weight_kernel<bf16>), G1(n), src, (bf16*)dst, (bf16*)dst_t, (bf16*)dst_phase, (int)co, (int)ci, (int)k, cs);
+    else if (dt == TAV_F32) hipLaunchKernelGGL((cast_conv_weight_kernel<float>), G1(n), src, (float*)dst, (float*)dst_t, (float*)dst_phase, (int)co, (int)ci, (int)k, cs);
+    else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+// v5: zero rows [0, pad) and [pad + T, T + 2 pad) of every [T + 2 pad][C] batch entry (the zero frame around a padded gradient buffer)
+template <typename T> __global__ void zero_pad_rows_kernel(T* __restrict__ buf, long n4, int Tn, int C, int pad) {
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= n4) return;
+    const int c4 = C / 4;
+    const long row = i4 / c4;                                // (b, pad row 0 .. 2 pad - 1)
+    const int col = (int)(i4 - row * c4) * 4;
+    const long b = row / (2 * pad);
+    const int pr = (int)(row - b * 2 * pad);
+    const long trow = b * ((long)Tn + 2 * pad) + (pr < pad ? pr : Tn + pr);
+    st4(buf + trow * C + col, f32x4{0.f, 0.f, 0.f, 0.f});
+}
+extern "C" int tav_zero_pad_rows(void* buf, int32_t dt, int64_t B, int64_t T, int64_t C, int64_t pad, void* stream) {
+    if (!buf) return TAV_ERR_NULL;
+    if (B <= 0 || T <= 0 || C <= 0 || C % 4 || pad <= 0) return TAV_ERR_SHAPE;
+    const long n4 = B * 2 * pad * (C / 4);
+    if (dt == TAV_BF16) hipLaunchKernelGGL((zero_pad_rows_kernel<bf16>), G1(n4), (bf16*)buf, n4, (int)T, (int)C, (int)pad);
+    else if (dt == TAV_F32) hipLaunchKernelGGL((zero_pad_rows_kernel<float>), G1(n4), (float*)buf, n4, (int)T, (int)C, (int)pad);
     else return TAV_ERR_DTYPE;
     return tav_last_error();
 }

@@ -30,6 +30,7 @@ struct GemmNT {
     long lda, ldb, ldc, ld_pre, ld_gelu, ld_resid;   // row strides in elements
     int nzg;
     long a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg;  // batch strides in elements (C strides apply to Cpre/gelu_in/resid too)
+    long g_zb;                                         // ... except that gelu_in takes this zb stride (= c_zb unless the caller says otherwise: ABI v5 gelu_zb)
     int act, accumulate;
     float alpha;
     int tiles_m, tiles_n;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) __attribute__((amdgpu_wav
     const long coff = zb * p.c_zb + zg * p.c_zg;
     TO* C = reinterpret_cast<TO*>(p.C) + coff;
     TO* Cpre = p.Cpre ? reinterpret_cast<TO*>(p.Cpre) + coff : nullptr;
-    const TS* Gin = p.gelu_in ? reinterpret_cast<const TS*>(p.gelu_in) + coff : nullptr;
+    const TS* Gin = p.gelu_in ? reinterpret_cast<const TS*>(p.gelu_in) + (zb * p.g_zb + zg * p.c_zg) : nullptr;
     const float alpha = p.alpha * (p.sa ? *p.sa : 1.f) * (p.sb ? *p.sb : 1.f);
     const float* R = p.resid ? p.resid + coff : nullptr;
     // What the epilogue does is a launch-time constant.  EPI = NT_GEN reads it from the arguments (any combination); the four flavours the
@@ -1091,7 +1092,7 @@ static int nt_validate(const tav_gemm_nt_args* a, bool need_ptrs) {
     }
     const int pk = 16 / es;
     if (a->lda % pk || a->ldb % pk || a->ldc % 4) return TAV_ERR_ALIGN;
-    if (a->a_zb % pk || a->a_zg % pk || a->b_zb % pk || a->b_zg % pk || a->c_zb % 4 || a->c_zg % 4) return TAV_ERR_ALIGN;
+    if (a->a_zb % pk || a->a_zg % pk || a->b_zb % pk || a->b_zg % pk || a->c_zb % 4 || a->c_zg % 4 || a->gelu_zb % 4) return TAV_ERR_ALIGN;
     return 0;
 }
 // The tile plan of one call: `tm` for the first `rows_big` rows (all of them unless a mixed schedule wins), `tm_rest` for the others.
@@ -1136,6 +1137,7 @@ extern "C" int tav_gemm_nt(const tav_gemm_nt_args* a, void* stream_) {
     p.nzg = a->nzg > 0 ? a->nzg : 1;
     const int nzb = a->nzb > 0 ? a->nzb : 1;
     p.a_zb = a->a_zb; p.a_zg = a->a_zg; p.b_zb = a->b_zb; p.b_zg = a->b_zg; p.c_zb = a->c_zb; p.c_zg = a->c_zg; p.bias_zg = a->bias_zg;
+    p.g_zb = a->gelu_zb ? a->gelu_zb : a->c_zb;
     p.act = a->act; p.accumulate = a->accumulate; p.alpha = a->alpha;
     p.sa = a->in_dtype == TAV_FP8 ? a->a_dequant : nullptr; p.sb = a->in_dtype == TAV_FP8 ? a->b_dequant : nullptr;
     const int in_dtype = a->in_dtype, out_dtype = a->out_dtype;

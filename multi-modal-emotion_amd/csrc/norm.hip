@@ -169,6 +169,37 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
     }
 }
 
+// Deferred form (ABI v5): a step has ~210 LayerNorm backwards, each followed by its own 48-workgroup reduce launch (4-5 us + the gap around
+// it: 2.5 ms of serial time per step for 3 MB each).  Nobody reads dgamma / dbeta before the optimizer, so the host may keep every
+// LayerNorm's partial slab and reduce up to 64 of them in ONE launch at the end of the backward (ops.ln_flush): grid.y = item.
+struct LnReduceBatch { tav_ln_reduce_item it[TAV_LN_REDUCE_MAX]; };
+__global__ __launch_bounds__(256) void ln_param_reduce_multi_kernel(const LnReduceBatch b) {
+    __shared__ float red[64][16][2];
+    const tav_ln_reduce_item& it = b.it[blockIdx.y];
+    const int W = it.W, nblocks = it.nblocks;
+    if ((int)blockIdx.x * 16 >= W) return;                       // (grid.x covers the widest item; uniform per workgroup)
+    const float* __restrict__ partials = it.partials;
+    const int cq = threadIdx.x & 3, rg = threadIdx.x >> 2, c = blockIdx.x * 16 + 4 * cq;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, bsum = g;
+    if (c < W) {
+#pragma unroll 4
+        for (int k = rg; k < nblocks; k += 64) { g += ld4(partials + ((long)k * 2 + 0) * W + c); bsum += ld4(partials + ((long)k * 2 + 1) * W + c); }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[rg][4 * cq + e][0] = g[e]; red[rg][4 * cq + e][1] = bsum[e]; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int l = threadIdx.x, cc = blockIdx.x * 16 + l;
+        if (cc < W) {
+            float sg = 0.f, sb = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) { sg += red[k][l][0]; sb += red[k][l][1]; }      // same summation order as ln_param_reduce_kernel: bitwise equal results
+            if (it.dgamma) it.dgamma[cc] = it.accumulate ? it.dgamma[cc] + sg : sg;
+            if (it.dbeta) it.dbeta[cc] = it.accumulate ? it.dbeta[cc] + sb : sb;
+        }
+    }
+}
+
 // cap on workgroups of the LN backward (= rows of the dgamma/dbeta partial buffer).  Measured at 11712 x 768: 256 -> 35.5 us,
 // 512 -> 33.9 us, 1024 -> 38.0 us (more partial rows for ln_param_reduce); at 46848 x 768 (batch 32): 256 -> 157 us, 512 -> 106.5 us
 // (4.7 TB/s), 1024 -> 131 us, 2048 -> 136 us: one workgroup per CU keeps too few bytes in flight, four pay for their partial rows.
@@ -385,7 +416,8 @@ extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
     if (a->rows <= 0 || a->W <= 0 || a->W > 1024 || a->W % 4) return TAV_ERR_SHAPE;
     if (a->ld_x % 4 || a->ld_dy % 4 || a->ld_dx % 4) return TAV_ERR_ALIGN;
     LnP p = pack(a);
-    if (!a->dgamma && !a->dbeta) p.partials = nullptr;
+    if (!a->dgamma && !a->dbeta && !a->defer_param_reduce) p.partials = nullptr;
+    if (a->defer_param_reduce && !a->partials) return TAV_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int nb = ln_blocks(a->rows);
     dim3 grid(nb), block(256);
@@ -403,12 +435,29 @@ extern "C" int tav_ln_bwd(const tav_ln_args* a, void* stream) {
 #undef TAV_LN_BWD
     int e = (int)hipGetLastError();
     if (e) return e;
-    if (p.partials) {
+    if (p.partials && !a->defer_param_reduce) {
         hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(tav_cdiv(a->W, 16)), dim3(256), 0, st, a->partials, a->dgamma, a->dbeta, nb, (int)a->W,
                            a->accumulate_params);
         e = (int)hipGetLastError();
     }
     return e;
+}
+
+extern "C" int tav_ln_param_reduce_multi(const tav_ln_reduce_item* items, int32_t n, void* stream) {
+    if (!items) return TAV_ERR_NULL;
+    if (n <= 0 || n > TAV_LN_REDUCE_MAX) return TAV_ERR_SHAPE;
+    LnReduceBatch b;
+    int wmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const tav_ln_reduce_item& it = items[i];
+        if (!it.partials || (!it.dgamma && !it.dbeta)) return TAV_ERR_NULL;
+        if (it.W <= 0 || it.W > 1024 || it.W % 4 || it.nblocks <= 0 || it.nblocks > LN_MAX_BLOCKS) return TAV_ERR_SHAPE;
+        b.it[i] = it;
+        wmax = it.W > wmax ? it.W : wmax;
+    }
+    for (int i = n; i < TAV_LN_REDUCE_MAX; ++i) b.it[i] = tav_ln_reduce_item{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(ln_param_reduce_multi_kernel, dim3(tav_cdiv(wmax, 16), n), dim3(256), 0, (hipStream_t)stream, b);
+    return (int)hipGetLastError();
 }
 
 extern "C" int tav_gn_workspace_floats(int64_t B, int64_t C) { return (int)(B * GN_SPLIT * C * 2 + B * C * 2); }

@@ -40,6 +40,7 @@ class BucketedAllReduce:
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"    # RCCL has AVG; gloo sums then scales
         self.side = torch.cuda.Stream() if self._cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p in self.params]
+        self._sync_ln_defer()
 
     # ---- bucket planning -------------------------------------------------------------------------------------------
     def _plan(self, order):
@@ -173,6 +174,7 @@ class BucketedAllReduce:
         """Graph mode on/off.  Turning it on drops the learned bucket plan: pack_all() re-plans from the parameter list order, which
         is identical on every rank by construction (and may use larger buckets: nothing overlaps in this mode)."""
         self._manual = bool(on)
+        self._sync_ln_defer()
         if on:
             self.buckets = None
             self._pending, self._works, self._ready = {}, [], []
@@ -213,6 +215,14 @@ class BucketedAllReduce:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        self._hooks = []
+        self._sync_ln_defer()
+
+    def _sync_ln_defer(self):
+        """Hook mode packs a gradient the moment autograd has accumulated it -- before the backward pass ends -- so the LayerNorm parameter
+        gradients must be complete then: the deferred second stage (ops.ln_flush, run when the pass ends) is switched off while hooks are live."""
+        from . import ops
+        ops.ln_defer[0] = not (self._active and not self._manual and bool(self._hooks))
 
 
 # ====================================================================================================================
@@ -336,6 +346,7 @@ class GraphedStep:
         with runtime.capture(self.gu, stream, pool=g0.pool(), **mode):
             stepper.update()
         self._adopt_buckets()
+        self.check_plan_across_ranks()
 
     def _adopt_buckets(self):
         red = self.red
@@ -433,8 +444,24 @@ class GraphedStep:
 
     def bucket_signature(self):
         """[(number of parameters, total elements)] per bucket: must be identical on every rank (each rank derives its buckets from
-        its own autograd graph; tests and bench.py compare this across ranks before the first collective)."""
+        its own autograd graph; check_plan_across_ranks() compares it on every rank before the chain's first replay -- bench.py gets that
+        through GraphedStep.__init__ -- and the two-rank tests compare it explicitly)."""
         return [(len(pl), int(sum(p.numel() for p in pl))) for pl, _ in self.flats]
+
+    def check_plan_across_ranks(self):
+        """Every rank derives its buckets from its OWN autograd walk and arena reordering; two ranks that disagree would pair differently
+        sized all-reduces (a hang, or buckets mixed up, with no diagnosis).  Gather the plans once, before the first collective of the
+        chain, and raise on every rank if they differ.  Called by __init__ (graph mode) / after the first eager pass; one small object
+        collective, outside any capture and outside the timed region."""
+        red = self.red
+        if not (dist.is_available() and dist.is_initialized()) or not red._active or red.world <= 1:
+            return
+        mine = self.bucket_signature()
+        plans = [None] * red.world
+        dist.all_gather_object(plans, mine, group=red.pg)
+        if any(p != plans[0] for p in plans):
+            raise RuntimeError("data-parallel bucket plans differ across ranks (rank: [(parameters, elements) per bucket]): "
+                               + "; ".join(f"{r}: {p}" for r, p in enumerate(plans)))
 
     def _reduce(self, flat):
         red = self.red
@@ -487,6 +514,7 @@ class GraphedStep:
         if self._plan is None:
             self._plan = sig
             self._adopt_buckets()
+            self.check_plan_across_ranks()
         elif sig != self._plan:
             raise RuntimeError(f"data-parallel bucket plan changed between steps: {self._plan} -> {sig}")
         self.stepper.update()

@@ -157,9 +157,9 @@ class WeightCache:
             return tuple(ops.fp8_quantize(w, want_t=True) for w in (wqkv, wo_n, w1_n, w2_n))
         return self._get(("layer_fp8", id(wq)), (wq, wk, wv, wo, w1, w2), build)
 
-    def conv(self, w):
-        """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], dgrad operand [k*ci, co])."""
-        return self._get(("conv", id(w)), (w,), lambda: ops.cast_conv_weight(w.detach(), self.pol.lp))
+    def conv(self, w, stride=0):
+        """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], column-buffer dgrad operand [k*ci, co], per-phase dgrad operands or None)."""
+        return self._get(("conv", id(w), int(stride)), (w,), lambda: ops.cast_conv_weight(w.detach(), self.pol.lp, stride))
 
     def posconv(self, v, g):
         """weight-normed grouped conv -> (w [G,Cg,K*Cg], flipped dgrad form, norms [K])."""
@@ -746,6 +746,12 @@ class GroupNormGeluFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+# Input gradient of the strided convs without a column buffer (round 4; 0 = the NT GEMM into [T_out, k*Ci] + col2im of rounds 1-3).
+CONV_PHASE_DGRAD = [os.environ.get("TAV_CONV_PHASE", "1") == "1"]
+CONV_PAD = 2                  # zero rows in front of and behind every batch entry of a padded gradient buffer (covers k <= 3 * stride taps)
+_CONV_PADDED = {}             # data_ptr of a padded buffer's interior view -> the buffer, from the layer that wrote it to the one that reads it
+
+
 class ConvGemmFn(torch.autograd.Function):
     """Conv1d(C_in, C_out, k, stride) on channels-last [B, T_in, C_in] as one NT GEMM over overlapping rows
     (lda = stride*C_in, K = k*C_in), optional bias and fused exact GELU; gradients: TN GEMM (dW), NT GEMM + col2im (dx).
@@ -761,7 +767,9 @@ class ConvGemmFn(torch.autograd.Function):
         B, T_in, Ci = x.shape
         Co, _, k = w.shape
         T_out = (T_in - k) // stride + 1
-        w_n, _ = ectx.cache.conv(w)
+        w_n = ectx.cache.conv(w, stride)[0]
+        if u_in is None:
+            _CONV_PADDED.clear()                            # (first conv of a stack, forward: nothing of an earlier backward is still wanted)
         res = ops.gemm_nt(x, w_n, bias=b, act=1 if gelu else 0, want_pre=gelu, M=T_out, N=Co, K=k * Ci, lda=stride * Ci, ldb=k * Ci, ldc=Co,
                           nzb=B, a_zb=T_in * Ci, c_zb=T_out * Co, out_shape=(B, T_out, Co))
         y, pre = res if gelu else (res, None)
@@ -775,21 +783,64 @@ class ConvGemmFn(torch.autograd.Function):
     def backward(ctx, g, g_pre):
         x, w, pre, u_in = ctx.saved_tensors
         B, T_in, Ci, Co, k, stride, T_out = ctx.geom
-        du = _c(g_pre) if g_pre is not None else None          # from a chained consumer: already times gelu'(pre)
+        du = g_pre                                              # from a chained consumer: already times gelu'(pre); possibly a view of a padded buffer
         if g is not None:
             d2 = ops.gelu_bwd(pre, _c(g)) if pre is not None else _c(g)
-            du = d2 if du is None else du + d2
+            du = d2 if du is None else _c(du) + d2
         if du is None:
             return None, None, None, None, None, None, None
-        _, w_t = ctx.ectx.cache.conv(w)
+        _, w_t, w_ph = ctx.ectx.cache.conv(w, stride)
+        P = CONV_PAD
+        TP = T_out + 2 * P
+        # `du` in PADDED form [B, P + T_out + P, Co] with zero frames (what the phase GEMMs below read past the ends): either this layer's
+        # chained consumer produced it that way (its `dui`, recognised by its storage), or -- small tensors only -- it is copied into one here.
+        du_pad = _CONV_PADDED.pop(du.data_ptr(), None) if g is None else None
+        if du_pad is not None and (tuple(du.shape) != (B, T_out, Co) or tuple(du.stride()) != (TP * Co, Co, 1) or tuple(du_pad.shape) != (B, TP, Co)):
+            du_pad = None
+        want_dx = ctx.needs_input_grad[1] if ctx.chained else ctx.needs_input_grad[0]
+        phase = (CONV_PHASE_DGRAD[0] and w_ph is not None and want_dx and (k + stride - 1) // stride - 1 <= P        # taps behind / rows past the end
+                 and (T_in - 1) // stride + 1 <= T_out + P)                                                         # ... stay inside the zero frames
+        if du_pad is None:
+            du = _c(du)
+            if phase and du.numel() <= (1 << 23):
+                du_pad = ops.zero_pad_rows(torch.empty(B, TP, Co, dtype=du.dtype, device=du.device), B, T_out, Co, P)
+                du_pad[:, P:P + T_out].copy_(du)
+            else:
+                phase = False
+        du_v = du_pad[:, P:P + T_out] if du_pad is not None else du                 # [B, T_out, Co], batch stride za
+        za = TP * Co if du_pad is not None else T_out * Co
         dw = db = dx = dui = None
         if ctx.needs_input_grad[2]:
-            dw = ops.gemm_tn(du, x, N1=Co, N2=k * Ci, lda=Co, ldb=stride * Ci, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Co, b_zb=T_in * Ci,
+            dw = ops.gemm_tn(du_v, x, N1=Co, N2=k * Ci, lda=Co, ldb=stride * Ci, rows_per_batch=T_out, nbatch=B, a_zb=za, b_zb=T_in * Ci,
                              perm_inner=Ci, perm_outer=k, out_shape=(Co, Ci, k))
         if ctx.has_b and ctx.needs_input_grad[3]:
-            db = ops.colsum(du.view(B * T_out, Co))
-        if ctx.needs_input_grad[1] if ctx.chained else ctx.needs_input_grad[0]:
-            dcol = ops.gemm_nt(du.view(B * T_out, Co), w_t, out_shape=(B * T_out, k * Ci))
+            db = ops.colsum(du_pad.view(B * TP, Co) if du_pad is not None else du.view(B * T_out, Co))     # (the zero frames add nothing)
+        if want_dx and phase:
+            # dx[s*m + r] = sum_q dy[m - q] . W[:, :, r + q*s]: per residue r ONE NT GEMM over Q_r consecutive rows of the padded dy (overlapping
+            # rows, lda = Co, K = Q_r * Co) that writes every s-th row of dx -- no [T_out, k*Ci] column buffer, no col2im pass, f32 accumulation
+            # over the taps.  A chained layer multiplies by gelu'(u_in) in the epilogue and writes into the NEXT padded buffer.
+            if ctx.chained:
+                out = ops.zero_pad_rows(torch.empty(B, T_in + 2 * P, Ci, dtype=du_v.dtype, device=du_v.device), B, T_in, Ci, P)
+                zc, obase = (T_in + 2 * P) * Ci, P * Ci
+            else:
+                out = torch.empty(B, T_in, Ci, dtype=du_v.dtype, device=du_v.device)
+                zc, obase = T_in * Ci, 0
+            oflat, aflat, uflat = out.view(-1), du_pad.view(-1), (u_in.reshape(-1) if ctx.chained else None)
+            off = 0
+            for r in range(stride):
+                Q = (k - r + stride - 1) // stride
+                Mr = (T_in - r + stride - 1) // stride
+                ops.gemm_nt(aflat[(P - (Q - 1)) * Co:], w_ph[off:off + Ci * Q * Co], out=oflat[obase + r * Ci:], M=Mr, N=Ci, K=Q * Co, lda=Co, ldb=Q * Co,
+                            ldc=stride * Ci, nzb=B, a_zb=TP * Co, c_zb=zc, gelu_in=uflat[r * Ci:] if ctx.chained else None,
+                            ld_gelu=stride * Ci, gelu_zb=T_in * Ci)
+                off += Ci * Q * Co
+            if ctx.chained:
+                dui = out[:, P:P + T_in]
+                _CONV_PADDED[dui.data_ptr()] = out
+            else:
+                dx = out
+        elif want_dx:
+            dcol = ops.gemm_nt(_c(du_v).view(B * T_out, Co), w_t, out_shape=(B * T_out, k * Ci))
             d = ops.col2im_1d(dcol, B, T_in, T_out, Ci, k, stride, pre_act=u_in if ctx.chained else None)
             if ctx.chained:
                 dui = d

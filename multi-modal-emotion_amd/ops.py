@@ -4,6 +4,7 @@ No arithmetic happens here; torch is used for device memory and streams only.  S
 (name, stream) so that concurrent branches on different HIP streams never share a workspace.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -74,7 +75,8 @@ def profile_stop(select="bf16"):
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None, want_pre=False, out=None,
             accumulate=False, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
-            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None, tile_m=0, a_dequant=None, b_dequant=None):
+            nzb=1, nzg=1, a_zb=0, a_zg=0, b_zb=0, b_zg=0, c_zb=0, c_zg=0, bias_zg=0, out_shape=None, tile_m=0, a_dequant=None, b_dequant=None,
+            ld_gelu=None, gelu_zb=0):
     """C = epi(alpha * A @ B^T).  Plain use: a [M,K], b [N,K] contiguous.  Strided/batched use: pass sizes/strides.
     fp8 operands (torch.float8_e4m3fn): pass their dequantisation scalars (Fp8.dequant) and an explicit out_dtype."""
     if M is None:
@@ -92,7 +94,8 @@ def gemm_nt(a, b, *, bias=None, act=0, resid=None, gelu_in=None, out_dtype=None,
     g.bias, g.gelu_in, g.resid = ptr(bias), ptr(gelu_in), ptr(resid)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc, g.ld_pre = lda, ldb, ldc, ldc
-    g.ld_gelu_in = gelu_in.stride(-2) if gelu_in is not None else 0
+    g.ld_gelu_in = (ld_gelu if ld_gelu is not None else gelu_in.stride(-2)) if gelu_in is not None else 0
+    g.gelu_zb = gelu_zb
     g.ld_resid = resid.stride(-2) if resid is not None else 0
     g.nzb, g.nzg = nzb, nzg
     g.a_zb, g.a_zg, g.b_zb, g.b_zg, g.c_zb, g.c_zg, g.bias_zg = a_zb, a_zg, b_zb, b_zg, c_zb, c_zg, bias_zg
@@ -328,26 +331,88 @@ def ln_fwd(x, gamma, beta, eps, *, want_f32=True, lp_dtype=None, act=0):
     return y32, ylp, mean, rstd
 
 
+# Deferred second stage of the LayerNorm backward.  Inside an autograd backward pass nobody reads dgamma / dbeta before the pass ends (they
+# flow straight into AccumulateGrad), so every LayerNorm keeps its own partial slab and ONE launch per 64 of them reduces the lot from a
+# callback the engine runs when the pass is over -- on the caller's stream, after it has been synchronised with every stream a gradient was
+# produced on (torch/csrc/autograd/engine.cpp, GraphTask::exec_post_processing), hence also under multi-stream capture.  ~210 launches per step
+# become 4.  Off (immediate reduce) outside a backward pass and while a hook-mode reducer is active (ddp.BucketedAllReduce reads gradients
+# from post-accumulate hooks, i.e. before the pass ends).
+# What autograd does with a returned gradient decides the rest (torch/csrc/autograd/functions/accumulate_grad.h):
+#   * a parameter WITHOUT a gradient takes it over -- `grad = new_grad.detach()`, same storage -- provided nobody else holds the tensor: the
+#     pending list therefore keeps the STORAGES of dgamma / dbeta alive, never the tensors (a second reference would make AccumulateGrad
+#     clone the still unwritten buffer);
+#   * a parameter that already HAS a gradient is accumulated in place, at once: it reads the buffer -- so a LayerNorm whose gamma / beta
+#     carry a gradient (accumulation over several backwards, zero-filled gradients) is reduced immediately, not deferred.
+ln_defer = [os.environ.get("TAV_LN_DEFER", "1") == "1"]      # (TAV_LN_DEFER=0: the immediate two-launch form, for A/B runs)
+_ln_pending = {"task": -1, "items": []}
+
+
+def _graph_task_id():
+    try:
+        return torch._C._current_graph_task_id()
+    except Exception:
+        return -1
+
+
+def ln_flush():
+    """Reduce every pending LayerNorm's partial slab into its dgamma / dbeta (current stream)."""
+    items, _ln_pending["items"] = _ln_pending["items"], []
+    _ln_pending["task"] = -1
+    cur = torch.cuda.current_stream() if items and items[0][0].is_cuda else None
+    for i in range(0, len(items), L.LN_REDUCE_MAX):
+        chunk = items[i:i + L.LN_REDUCE_MAX]
+        arr = (L.LnReduceItem * len(chunk))()
+        for j, (part, dg_st, db_st, dg_ptr, db_ptr, nblk, W) in enumerate(chunk):
+            if cur is not None:              # allocated under a branch stream, used here: the allocator must not recycle them before this launch ran
+                part.record_stream(cur)
+                for st in (dg_st, db_st):
+                    torch.empty(0, dtype=torch.float32, device=part.device).set_(st).record_stream(cur)
+            arr[j].partials, arr[j].dgamma, arr[j].dbeta, arr[j].nblocks, arr[j].W, arr[j].accumulate = ptr(part), dg_ptr, db_ptr, nblk, W, 0
+        check(lib().tav_ln_param_reduce_multi(arr, len(chunk), stream()), "ln_param_reduce_multi")
+
+
+def _ln_defer_register(part, dgamma, dbeta, nblk, W):
+    tid = _graph_task_id()
+    if _ln_pending["task"] != tid:
+        # a new backward pass (whatever an aborted earlier one left behind is dropped: its gradients were never consumed)
+        _ln_pending["task"], _ln_pending["items"] = tid, []
+        torch.autograd.Variable._execution_engine.queue_callback(ln_flush)
+    _ln_pending["items"].append((part, dgamma.untyped_storage(), dbeta.untyped_storage(), dgamma.data_ptr(), dbeta.data_ptr(), nblk, W))
+
+
+def _grad_free_leaf(p):
+    return bool(getattr(p, "is_leaf", False)) and p.grad is None
+
+
 def ln_bwd(dy, x, gamma, beta, mean, rstd, *, dx_add=None, want_f32=True, lp_dtype=None, act=0, param_grads=True):
     """Returns (dx_f32 | None, dx_lp | None, dgamma, dbeta)."""
     rows, W = x.shape
     dx32 = torch.empty(rows, W, dtype=torch.float32, device=x.device) if want_f32 else None
     dxlp = torch.empty(rows, W, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
     dgamma = dbeta = part = None
+    defer = False
     if param_grads:
         dgamma = torch.empty(W, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(W, dtype=torch.float32, device=x.device)
-        part = workspace("ln_part", lib().tav_ln_bwd_partials(rows) * 2 * W, x.device)
+        nblk = lib().tav_ln_bwd_partials(rows)
+        defer = ln_defer[0] and _graph_task_id() >= 0 and _grad_free_leaf(gamma) and _grad_free_leaf(beta)
+        if defer:
+            part = torch.empty(nblk * 2 * W, dtype=torch.float32, device=x.device)      # its own slab: alive until ln_flush()
+        else:
+            part = workspace("ln_part", nblk * 2 * W, x.device)
     a = L.LnArgs()
     a.x, a.x_dtype, a.gamma, a.beta = ptr(x), dt(x), ptr(gamma), ptr(beta)
     a.mean, a.rstd = ptr(mean), ptr(rstd)
     a.dy, a.dy_dtype, a.dx_add = ptr(dy), dt(dy), ptr(dx_add)
     a.dx_f32, a.dx_lp, a.lp_dtype = ptr(dx32), ptr(dxlp), dt(lp_dtype) if lp_dtype is not None else 0
     a.dgamma, a.dbeta, a.partials, a.accumulate_params = ptr(dgamma), ptr(dbeta), ptr(part), 0
+    a.defer_param_reduce = int(defer)
     a.rows, a.W, a.ld_x, a.ld_dy, a.ld_dx, a.act = rows, W, x.stride(0), dy.stride(0), W, act
     nb = rows * W * (x.element_size() + dy.element_size() + (4 if dx_add is not None else 0) + (4 if want_f32 else 0)
                      + (dxlp.element_size() if dxlp is not None else 0)) + rows * 8
     _prof_launch("ln", "hbm", 0.0, nb, lambda: check(lib().tav_ln_bwd(C.byref(a), stream()), "ln_bwd"))
+    if defer:
+        _ln_defer_register(part, dgamma, dbeta, nblk, W)
     return dx32, dxlp, dgamma, dbeta
 
 
@@ -383,12 +448,21 @@ def cast_weights_multi(descs, n, blocks_per_tensor=96):
     check(lib().tav_cast_weights_multi(ptr(descs), n, blocks_per_tensor, stream()), "cast_weights_multi")
 
 
-def cast_conv_weight(w, dtype):
+def cast_conv_weight(w, dtype, conv_stride=0):
+    """-> (forward operand [co, k*ci], column-buffer dgrad operand [k*ci, co], per-phase dgrad operands flat [co*ci*k] or None).
+    conv_stride > 0 asks for the phase operands (tav_cast_conv_weight, include/tavhip.h)."""
     co, ci, k = w.shape
     n = torch.empty(co, k * ci, dtype=dtype, device=w.device)
     t = torch.empty(k * ci, co, dtype=dtype, device=w.device)
-    check(lib().tav_cast_conv_weight(ptr(w), co, ci, k, ptr(n), ptr(t), dt(dtype), stream()), "cast_conv_weight")
-    return n, t
+    ph = torch.empty(co * ci * k, dtype=dtype, device=w.device) if conv_stride and conv_stride <= k else None
+    check(lib().tav_cast_conv_weight(ptr(w), co, ci, k, ptr(n), ptr(t), ptr(ph), conv_stride if ph is not None else 0, dt(dtype), stream()), "cast_conv_weight")
+    return n, t, ph
+
+
+def zero_pad_rows(buf, B, T, Cc, pad):
+    """Zero the `pad` leading and trailing rows of each of the B entries of a [B, T + 2*pad, Cc] buffer."""
+    check(lib().tav_zero_pad_rows(ptr(buf), dt(buf), B, T, Cc, pad, stream()), "zero_pad_rows")
+    return buf
 
 
 def cast2d(x, dtype, out=None):

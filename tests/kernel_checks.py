@@ -211,7 +211,7 @@ def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
     T_out = (T_in - k) // s + 1
     x = _rnd(B, T_in, Cc, dtype=dtype, seed=10)
     w = _rnd(Cc, Cc, k, scale=0.1, seed=11)              # nn.Conv1d layout [co][ci][k], f32 parameter
-    wn, wt = ops.cast_conv_weight(w, dtype)
+    wn, wt, _ = ops.cast_conv_weight(w, dtype)
     y, pre = ops.gemm_nt(x, wn, act=1, want_pre=True, M=T_out, N=Cc, K=k * Cc, lda=s * Cc, ldb=k * Cc, ldc=Cc,
                          nzb=B, a_zb=T_in * Cc, c_zb=T_out * Cc, out_shape=(B, T_out, Cc))
     xr = x.float().permute(0, 2, 1).requires_grad_(True)
@@ -229,6 +229,50 @@ def check_conv_as_gemm(dtype, B=2, T_in=203, Cc=64, k=3, s=2):
     dw = ops.gemm_tn(du, x, N1=Cc, N2=k * Cc, lda=Cc, ldb=s * Cc, rows_per_batch=T_out, nbatch=B, a_zb=T_out * Cc,
                      b_zb=T_in * Cc, perm_inner=Cc, perm_outer=k, out_shape=(Cc, Cc, k))
     rs.append(_res(f"conv_gemm.dw[{dtype}]", dw, wr.grad, 1e-2 if dtype == torch.bfloat16 else 2e-5))
+    return rs
+
+
+def check_conv_chain(dtype, B=3, T=407, Cc=64):
+    """engine.ConvGemmFn as the wav2vec2 feature extractor chains it (HF wav2vec2:382-419, preset B: conv -> GELU, k = 3, 3, 2 at stride 2): the
+    round-4 input gradient -- one NT GEMM per output phase over a zero-framed dy, gelu' in the epilogue, no column buffer / col2im -- against
+    torch's conv1d autograd, and against the column-buffer path of rounds 1-3 (same products: bf16 differs only by where it rounds)."""
+    from tav_amd import engine as E
+    from tav_amd import runtime
+    ectx = E.Ctx("fp32" if dtype == torch.float32 else "bf16")
+    ks = [(3, 2), (3, 2), (2, 2)]
+    ws = [torch.nn.Parameter(_rnd(Cc, Cc, k, scale=0.12, seed=300 + i)) for i, (k, _) in enumerate(ks)]
+    bs = [torch.nn.Parameter(_rnd(Cc, scale=0.1, seed=310 + i)) for i in range(3)]
+    x0 = _rnd(B, T, Cc, dtype=dtype, seed=320)
+
+    def run(phase):
+        E.CONV_PHASE_DGRAD[0] = phase
+        for p_ in ws + bs:
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        h, u = x, None
+        for (k, st), w, b in zip(ks, ws, bs):
+            h, u = E.ConvGemmFn.apply(h, u, w, b, st, True, ectx)
+        (h.float() * h.float()).sum().backward()
+        return h.detach(), x.grad.detach(), [w.grad.detach().clone() for w in ws], [b.grad.detach().clone() for b in bs]
+    try:
+        y1, dx1, dw1, db1 = run(True)
+        y0, dx0, dw0, db0 = run(False)
+    finally:
+        E.CONV_PHASE_DGRAD[0] = True
+    xr = x0.float().permute(0, 2, 1).requires_grad_(True)
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    br = [b.detach().clone().requires_grad_(True) for b in bs]
+    h = xr
+    for (k, st), w, b in zip(ks, wr, br):
+        h = F.gelu(F.conv1d(h, w if dtype == torch.float32 else w.to(dtype).float(), b, stride=st))
+    (h * h).sum().backward()
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-5
+    rs = [_res(f"conv_chain.y[{dtype}]", y1, h.permute(0, 2, 1), tol), _res(f"conv_chain.dx phase[{dtype}]", dx1, xr.grad.permute(0, 2, 1), tol),
+          _res(f"conv_chain.dx col2im[{dtype}]", dx0, xr.grad.permute(0, 2, 1), tol)]
+    for i in range(3):
+        rs.append(_res(f"conv_chain.dw{i} phase[{dtype}]", dw1[i], wr[i].grad, tol))
+        rs.append(_res(f"conv_chain.db{i} phase[{dtype}]", db1[i], br[i].grad, tol))
+        rs.append(_res(f"conv_chain.dw{i} phase vs col2im[{dtype}]", dw1[i], dw0[i], tol))
     return rs
 
 
@@ -324,6 +368,49 @@ def check_layernorm(x_dtype, W=768, rows=333, act=0):
     rs += [_res("ln.dx", dx32, xr.grad + add, 5e-5), _res("ln.dx.lp", dxlp, xr.grad + add, 1e-2),
            _res("ln.dgamma", dg, gr.grad, 1e-4), _res("ln.dbeta", db, br.grad, 1e-4)]
     return rs
+
+
+def check_layernorm_deferred_param_reduce(n_ln=70):
+    """ABI v5: inside an autograd backward pass ops.ln_bwd keeps the per-workgroup column sums and ONE tav_ln_param_reduce_multi launch per 64
+    LayerNorms reduces them when the pass ends (ops.ln_flush, queued on the engine).  70 LayerNorms of three widths and ragged row counts
+    (two launches): dgamma / dbeta must equal the immediate two-stage form bit for bit, and nothing may be pending afterwards."""
+    cases = []
+    for i in range(n_ln):
+        W = (768, 512, 1024)[i % 3]
+        rows = 37 + 61 * i
+        x = _rnd(rows, W, seed=400 + i)
+        gamma, beta = _rnd(W, seed=401 + i) * 0.1 + 1.0, _rnd(W, seed=402 + i) * 0.1
+        _, _, mean, rstd = ops.ln_fwd(x, gamma, beta, 1e-5, want_f32=True, lp_dtype=None)
+        dy = _rnd(rows, W, seed=403 + i)
+        cases.append((x, gamma, beta, mean, rstd, dy))
+    assert ops._graph_task_id() < 0
+    want = [ops.ln_bwd(dy, x, g, b, m, r, want_f32=True)[2:] for (x, g, b, m, r, dy) in cases]       # outside a pass: immediate
+
+    class Ln(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, g, b, i):
+            ctx.i = i
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, g, b, m, r, _ = cases[ctx.i]
+            dx, _, dg, db = ops.ln_bwd(dy.contiguous(), x, g, b, m, r, want_f32=True)
+            return dx, dg, db, None
+
+    leaves, total = [], None
+    for i, (x, g, b, m, r, dy) in enumerate(cases):
+        gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        leaves.append((gp, bp))
+        t = (Ln.apply(x.clone().requires_grad_(True), gp, bp, i) * dy).sum()
+        total = t if total is None else total + t
+    total.backward()
+    torch.cuda.synchronize()
+    assert not ops._ln_pending["items"]
+    worst_g = max(float((gp.grad - w[0]).abs().max()) for (gp, _), w in zip(leaves, want))
+    worst_b = max(float((bp.grad - w[1]).abs().max()) for (_, bp), w in zip(leaves, want))
+    ok_g, ok_b = worst_g == 0.0, worst_b == 0.0
+    return [(f"ln.deferred dgamma bitwise x{n_ln}", worst_g, 0.0, ok_g), (f"ln.deferred dbeta bitwise x{n_ln}", worst_b, 0.0, ok_b)]
 
 
 # ------------------------------------------------------------------------------------------------ misc
@@ -570,6 +657,8 @@ def all_checks():
         out.append(lambda d=dtype: check_gemm_tn_grouped(d, M=64))
         out.append(lambda d=dtype: check_conv_as_gemm(d))
         out.append(lambda d=dtype: check_conv_as_gemm(d, k=2, T_in=100))
+        out.append(lambda d=dtype: check_conv_chain(d))
+        out.append(lambda d=dtype: check_conv_chain(d, B=2, T=1000, Cc=128))      # even length: the phases end on different rows
         for mode in (0, 1, 2):
             out.append(lambda d=dtype, m=mode: check_attention(d, m))
         out.append(lambda d=dtype: check_attention(d, 0, B=1, S=64, nh=1))
@@ -600,6 +689,8 @@ def all_checks():
         out.append(lambda d=dtype: check_layernorm(d))
         out.append(lambda d=dtype: check_layernorm(d, W=512, act=1))
         out.append(lambda d=dtype: check_layernorm(d, W=1024))
+        if dtype == torch.float32:
+            out.append(check_layernorm_deferred_param_reduce)
         out.append(lambda d=dtype: check_conv0_gn(d))
         out.append(lambda d=dtype: check_posconv(d))
     out.append(lambda: check_gemm_nt(torch.bfloat16, out_f32=True))

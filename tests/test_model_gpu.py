@@ -881,6 +881,9 @@ def test_c_abi_allreduce_bucket_single_rank(gpu):
     from tav_amd import _lib
     from tav_amd._lib import ptr, stream
     h = _lib.lib()
+    ver = ctypes.c_int32()
+    assert h.tav_comm_rccl_version(ctypes.byref(ver)) == 0 and ver.value >= 20000      # RCCL is resolved lazily (dlopen): which one did we get?
+    print(f"[c-abi collective] RCCL runtime version {ver.value} (header at build time: /opt/rocm/include/rccl/rccl.h)")
     uid = ctypes.create_string_buffer(128)
     assert h.tav_comm_unique_id(uid) == 0
     comm = ctypes.c_void_p()
@@ -892,6 +895,24 @@ def test_c_abi_allreduce_bucket_single_rank(gpu):
             assert h.tav_allreduce_bucket(ptr(x), x.numel() * x.element_size(), code, comm, stream()) == 0
             torch.cuda.synchronize()
             assert torch.equal(x, ref)                      # the mean over one rank
+        # ... and CAPTURED into a hipGraph on a side stream forked from the capture's origin (what ddp.GraphedStep's single-graph mode does):
+        # a raw RCCL call on the caller's stream, no process-group watchdog thread around it
+        x = torch.randn(1 << 20, device="cuda")
+        y = torch.empty_like(x)
+        origin, side = torch.cuda.Stream(), torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(origin):
+            with runtime.capture(g, origin, branches=[side], capture_error_mode="thread_local"):
+                y.copy_(x).mul_(2.0)
+                runtime.stream_wait(side, origin)
+                assert h.tav_allreduce_bucket(ptr(y), y.numel() * 4, 0, comm, side.cuda_stream) == 0
+                runtime.stream_wait(origin, side)
+                y.add_(1.0)
+        for k in range(3):
+            x.fill_(float(k))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y, torch.full_like(y, 2.0 * k + 1.0))
         assert h.tav_allreduce_bucket(None, 4, 0, comm, stream()) == -1 and h.tav_allreduce_bucket(ptr(x), 3, 0, comm, stream()) == -2
     finally:
         assert h.tav_comm_destroy(comm) == 0

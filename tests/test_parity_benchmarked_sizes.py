@@ -123,9 +123,10 @@ def test_batch32_equals_sixteen_oracle_checked_b2_runs_bf16(gpu):
     assert e_oracle < 1e-2, e_oracle
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1])
 def test_full_depth_bf16_more_seeds(gpu, seed):
-    """The bf16 full-depth gate on two more seeds (weights and inputs; seed 0 is test_full_depth_full_size_parity): the round-2 result sat at
+    """The bf16 full-depth gate on another seed (weights and inputs; seed 0 is test_full_depth_full_size_parity; seed 2 lives in
+    tools/gpu_seed_probe.py -- round 4 took it out of the suite, which spends its time in the CPU oracle): the round-2 result sat at
     8.2e-3 of a 1e-2 budget on one seed."""
     _compare_with_oracle(_oracle_full("B", seed=seed), "bf16", 1e-2, f"full-depth B seed {seed}")
 
@@ -141,3 +142,50 @@ def test_config5_full_depth_parity(gpu, policy, tol, gtol):
     encoder, 209 to the fusion stack), text 128, audio 5 s, every other stack at full depth, batch 2; fp32 / bf16 / fp8 policies against the
     fp32 CPU oracle (reference models/tav.py:456,480 scaled up; ~35 s of CPU for the oracle, shared by the three policies)."""
     _compare_with_oracle(_c5_oracle(), policy, tol, "config 5 full depth", grad_tol=gtol)
+
+
+def test_per_rank_batch4_full_depth_bf16(gpu):
+    """BASELINE configs[2] as ONE RANK sees it: global batch 32 over 8 GPUs = 4 utterances per rank, preset B, bf16, every stack at full depth,
+    full input sizes -- directly against the CPU oracle (logits, loss, clip_grad_norm_ value, every gradient; ~14 s of CPU).  The tile plans at
+    M = 4 x {128, 249, 481, 1464} tokens differ from the batch-2 and batch-8 cases (small-grid 4-deep rings, 128-wide weight-gradient tiles)."""
+    _compare_with_oracle(_oracle_full("B", seed=0, batch_size=4), "bf16", 1e-2, "full-depth B, batch 4 (one rank of configs[2])")
+
+
+def test_config0_text_classifier_b16_s128_full_depth_bf16(gpu):
+    """BASELINE configs[0] at its stated size: SingleModels/text_nn.py's classifier (reference SingleModels/models/text.py:41-69: BERT-base pooled
+    output -> Linear(768, 7)), 12 layers, batch 16, sequence 128 (last quarter of every row padded), bf16 policy against the fp32 CPU oracle:
+    logits, loss, clip_grad_norm_ value within 1e-2, every parameter gradient compared."""
+    from tav_amd.SingleModels.models.text import BertClassifier
+    from tav_amd.utils.global_functions import CrossEntropyLoss
+    cfg = C.preset("B")
+    assert cfg["text"]["layers"] == 12 and cfg["text"]["hidden"] == 768
+    runtime.set_precision("bf16")
+    model = BertClassifier(dict(output_dim=7, dropout=0.5), config=cfg)
+    synthetic.seeded_init_(model, 3)
+    (tx, _, _), lab = synthetic.make_batch(cfg, 16, s_text=128, text_only=True)
+    assert tx["input_ids"].shape == (16, 128) and float(tx["attention_mask"].sum()) < 16 * 128
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    o_logits = O.text_classifier_forward(sd, cfg, tx["input_ids"], tx["attention_mask"])
+    o_loss = torch.nn.functional.cross_entropy(o_logits, lab.long())
+    o_loss.backward()
+    o_grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    o_gn = torch.sqrt(sum((g.double() ** 2).sum() for g in o_grads.values())).item()
+    model.cuda()
+    logits = model(tx["input_ids"], tx["attention_mask"], "val")
+    loss = CrossEntropyLoss()(logits, lab.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    gn = grad_norm(list(model.parameters())).item()
+    e_logits, e_loss, e_gn = rel(logits.detach().cpu(), o_logits.detach()), abs(loss.item() - o_loss.item()) / abs(o_loss.item()), abs(gn - o_gn) / o_gn
+    gmax = max(g.abs().max().item() for g in o_grads.values())
+    worst, worst_k = 0.0, None
+    for k, p in model.named_parameters():
+        og = o_grads.get(k)
+        assert (p.grad is None) == (og is None), k
+        if og is not None:
+            e = (p.grad.detach().cpu() - og).abs().max().item() / (og.abs().max().item() + 1e-3 * gmax)
+            if e > worst:
+                worst, worst_k = e, k
+    print(f"[configs[0] text classifier b=16 S=128 12 L bf16] logits {e_logits:.2e} loss {e_loss:.2e} grad-norm {e_gn:.2e} worst tensor {worst:.2e} ({worst_k})")
+    assert e_logits < 1e-2 and e_loss < 1e-2 and e_gn < 1e-2, (e_logits, e_loss, e_gn)
+    assert worst < 5e-2, (worst, worst_k)

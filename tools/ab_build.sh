@@ -12,5 +12,5 @@ for f in gemm attention norm elementwise audio_frontend fp8 collective; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -I../../include "$@" -c $f.hip -o "$out/obj_$name/$f.o" &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/obj_$name"/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o "$out/$name.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$out/obj_$name"/*.o -ldl -o "$out/$name.so"
 echo "$out/$name.so"
