@@ -102,7 +102,13 @@ def parse_args():
                          "kernel alone on the device (the condition of the roofline pass); the utterances/s of such a run is not the headline")
     ap.add_argument("--branch-streams", type=int, default=-1,
                     help="1: text / audio / video encoders on their own HIP streams beside the fusion stack, 0: everything on one stream, -1: library default")
-    ap.add_argument("--ddp-segments", type=int, default=4, help="N > 1: backward graphs per step; bucket i is reduced on a side stream while graph i+1 runs")
+    ap.add_argument("--ddp-segments", type=int, default=4, help="N > 1: backward segments per step; bucket i is reduced on a side stream while segment i+1 runs")
+    ap.add_argument("--ddp-mode", default=os.environ.get("TAV_DDP_MODE", "auto"), choices=["auto", "single", "chain"],
+                    help="N > 1: 'single' = the whole step as ONE hipGraph with the bucket all-reduces captured as raw RCCL calls on the reducer branch "
+                         "(C ABI tav_allreduce_bucket); 'chain' = one graph per backward segment, torch.distributed all-reduces issued eagerly between "
+                         "them (rounds 2-3); 'auto' = chain: the single graph is 2 % faster with one rank on RCCL (18.5 vs 19.0 ms at 4 utterances per "
+                         "GPU, profiles/r04_ab_ddp.txt) but a captured collective has never met a second rank on this project, and a hang at N = 8 "
+                         "would cost the whole scaling measurement -- so the path that has run with two ranks stays the default")
     return ap.parse_args()
 
 
@@ -314,8 +320,12 @@ def main():
             fence()
             engine.bump_weight_epoch()
             stepper.opt.zero_grad()
-            gstep = GraphedStep(stepper, lambda: stepper.forward_loss(inp, labels, check="val", epoch=0, n_visual_true=n_true), work_stream,
-                                segments=args.ddp_segments)
+            fwd = lambda: stepper.forward_loss(inp, labels, check="val", epoch=0, n_visual_true=n_true)      # noqa: E731
+            gstep = None
+            if args.ddp_mode == "single":
+                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="single")
+            if gstep is None:
+                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="chain")
         except Exception as e:
             capture_failed(e)
         graph, one_step = gstep, gstep.run

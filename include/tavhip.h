@@ -132,6 +132,14 @@ int tav_fp8_amax(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64
  * token axis is padded with zeros up to rows_pad -- the K axis of the weight-gradient GEMM.  x is f32 or bf16, cols % 4 == 0. */
 int tav_fp8_quantize(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, const float* scales, void* q, int64_t ld_q, void* qt,
                      int64_t ld_qt, int64_t rows_pad, void* stream);
+/* v5, DELAYED scaling: `state` = 4 device floats {448/amax, amax/448, amax, running amax}.  tav_fp8_quantize_delayed quantises with state[0]
+ * -- the scale the previous step (or a calibration pass: tav_fp8_amax writes the first three) left there -- and gathers the tensor's own
+ * absolute maximum into state[3] on the way: one pass and one launch per tensor instead of three.  tav_fp8_roll_states, once per step after
+ * the last quantisation, turns every state[3] > 0 of the `n` consecutive states into the next step's scale and clears it.  state + 1 is the
+ * dequantisation factor tav_gemm_nt takes (a_dequant / b_dequant); it does not change within a step. */
+int tav_fp8_quantize_delayed(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, float* state, void* q, int64_t ld_q, void* qt,
+                             int64_t ld_qt, int64_t rows_pad, void* stream);
+int tav_fp8_roll_states(float* states, int64_t n, void* stream);
 /* out[i] (+)= sum_s slabs[s][i], s < nsplit, i < n_elems (n_elems % 4 == 0): fixed order, bitwise reproducible */
 int tav_splitk_reduce(const float* slabs, float* out, int32_t nsplit, int64_t n_elems, int32_t accumulate, void* stream);
 

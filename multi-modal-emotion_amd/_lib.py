@@ -83,6 +83,8 @@ _SIGS = {
     "tav_fp8_amax_partials": (C.c_int, [i64, i64]),
     "tav_fp8_amax": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, vp]),
     "tav_fp8_quantize": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, i64, vp]),
+    "tav_fp8_quantize_delayed": (C.c_int, [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, i64, vp]),
+    "tav_fp8_roll_states": (C.c_int, [vp, i64, vp]),
     "tav_splitk_reduce": (C.c_int, [vp, vp, i32, i64, i32, vp]),
     "tav_comm_rccl_version": (C.c_int, [C.POINTER(i32)]),
     "tav_comm_unique_id": (C.c_int, [vp]),

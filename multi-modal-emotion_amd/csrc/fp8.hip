@@ -56,23 +56,34 @@ TAV_DEV uint32_t pack4_fp8(f32x4 v) {
 }
 
 // 64 x 64 tiles: row-major copy with 4-byte stores (64-B row segments) and, through LDS, the transposed copy.
-template <typename T>
-__global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ x, const float* __restrict__ scales, uint8_t* __restrict__ q,
+// DELAYED (ABI v5, tav_fp8_quantize_delayed): `scales` is a 4-float STATE {448/amax, amax/448, amax, running amax of THIS pass}: the tensor is
+// quantised with the scale the previous step left there and its own absolute maximum is gathered on the way (one atomic max per wave on
+// state[3], as integer bits: |x| >= 0) for tav_fp8_roll_states to turn into the next step's scale -- ONE pass over the tensor (2 B read + 1 B
+// written per element) instead of the amax passes + the quantiser (2 + 2 + 1), and one launch instead of three.  Saturating conversion: a
+// value that outgrew last step's maximum clips to +-448.
+template <typename T, bool DELAYED>
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ x, float* __restrict__ scales, uint8_t* __restrict__ q,
                                                            uint8_t* __restrict__ qt, int rows, int cols, long ld, long ld_q, long ld_qt, int rows_pad) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[64][68];
     const float sc = scales[0];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int cq = threadIdx.x & 15, rh = threadIdx.x >> 4;           // 16 column groups of 4, 16 row slots
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + rh + 16 * i, c = c0 + 4 * cq;
         uint32_t w = 0;
         if (r < rows && c < cols) {
-            const f32x4 v = ld4(x + (long)r * ld + c) * sc;
-            w = pack4_fp8(v);
+            const f32x4 raw = ld4(x + (long)r * ld + c);
+            if constexpr (DELAYED) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(raw[0]), fabsf(raw[1])), fmaxf(fabsf(raw[2]), fabsf(raw[3]))));
+            w = pack4_fp8(raw * sc);
             if (q) *reinterpret_cast<uint32_t*>(q + (long)r * ld_q + c) = w;
         }
         *reinterpret_cast<uint32_t*>(&tile[rh + 16 * i][4 * cq]) = w;   // rows past the end stay zero: they are the K padding of qt
+    }
+    if constexpr (DELAYED) {
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(scales + 3), __float_as_uint(amax));
     }
     if (!qt) return;
     __syncthreads();
@@ -86,6 +97,16 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
             *reinterpret_cast<uint32_t*>(qt + (long)c * ld_qt + r) = w;
         }
     }
+}
+
+// every state whose running maximum moved this step takes it over as its scale; the others (unused this step, or just calibrated) stay
+__global__ void fp8_roll_states_kernel(float* __restrict__ states, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* st = states + 4l * i;
+    const float m = st[3];
+    if (m > 0.f && m < 3.0e38f) { st[0] = FP8_MAX / m; st[1] = m / FP8_MAX; st[2] = m; }
+    st[3] = 0.f;
 }
 
 __global__ void fp8_splitk_reduce_kernel(const float* __restrict__ S, float* __restrict__ out, int nsplit, long n4, int accumulate) {
@@ -124,9 +145,28 @@ extern "C" int tav_fp8_quantize(const void* x, int32_t dtype, int64_t rows, int6
     if (ld % 4 || (q && ld_q % 4) || (qt && (ld_qt % 4 || rows_pad % 4 || rows_pad < rows || ld_qt < rows_pad))) return TAV_ERR_ALIGN;
     const long rp = qt ? rows_pad : rows;
     dim3 grid(tav_cdiv(cols, 64), tav_cdiv(rp, 64));
-    if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16>), grid, dim3(256), 0, ST, (const bf16*)x, scales, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
-    else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float>), grid, dim3(256), 0, ST, (const float*)x, scales, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    float* sc = const_cast<float*>(scales);
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16, false>), grid, dim3(256), 0, ST, (const bf16*)x, sc, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float, false>), grid, dim3(256), 0, ST, (const float*)x, sc, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
     else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+extern "C" int tav_fp8_quantize_delayed(const void* x, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, float* state, void* q, int64_t ld_q,
+                                        void* qt, int64_t ld_qt, int64_t rows_pad, void* stream) {
+    if (!x || !state || (!q && !qt)) return TAV_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || cols % 4) return TAV_ERR_SHAPE;
+    if (ld % 4 || (q && ld_q % 4) || (qt && (ld_qt % 4 || rows_pad % 4 || rows_pad < rows || ld_qt < rows_pad))) return TAV_ERR_ALIGN;
+    const long rp = qt ? rows_pad : rows;
+    dim3 grid(tav_cdiv(cols, 64), tav_cdiv(rp, 64));
+    if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16, true>), grid, dim3(256), 0, ST, (const bf16*)x, state, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float, true>), grid, dim3(256), 0, ST, (const float*)x, state, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
+    else return TAV_ERR_DTYPE;
+    return tav_last_error();
+}
+extern "C" int tav_fp8_roll_states(float* states, int64_t n, void* stream) {
+    if (!states) return TAV_ERR_NULL;
+    if (n <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(fp8_roll_states_kernel, dim3(tav_cdiv(n, 256)), dim3(256), 0, ST, states, (int)n);
     return tav_last_error();
 }
 extern "C" int tav_splitk_reduce(const float* slabs, float* out, int32_t nsplit, int64_t n_elems, int32_t accumulate, void* stream) {

@@ -19,6 +19,39 @@ def _rt():
     from . import runtime          # (lazy: runtime imports engine, which imports this module's users)
     return runtime
 
+class AbiComm:
+    """An RCCL communicator owned through the C ABI (include/tavhip.h: tav_comm_*, tav_allreduce_bucket) next to the process group: a raw
+    ncclAllReduce on the CALLER's stream, which -- unlike a torch.distributed collective, whose process group keeps a watchdog thread
+    polling events -- can be captured into the step's hipGraph.  The 128-byte id travels from rank 0 over the existing process group."""
+
+    def __init__(self, pg, world, rank):
+        import ctypes
+        from ._lib import check, lib
+        h = lib()
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            check(h.tav_comm_unique_id(uid), "comm_unique_id")
+        if world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        self._h, self.comm = h, ctypes.c_void_p()
+        check(h.tav_comm_init_rank(ctypes.byref(self.comm), world, uid, rank), "comm_init_rank")       # collective: every rank is here
+        ver = ctypes.c_int32()
+        h.tav_comm_rccl_version(ctypes.byref(ver))
+        self.version = ver.value
+
+    def allreduce_mean(self, t, stream):
+        """In place, mean over the ranks, enqueued on `stream` (a torch.cuda.Stream); f32 or bf16."""
+        from ._lib import check, dt
+        check(self._h.tav_allreduce_bucket(t.data_ptr(), t.numel() * t.element_size(), dt(t), self.comm, stream.cuda_stream), "allreduce_bucket")
+
+    def destroy(self):
+        if self.comm is not None and self.comm.value:
+            self._h.tav_comm_destroy(self.comm)
+        self.comm = None
+
+
 class BucketedAllReduce:
     def __init__(self, params, bucket_mb=48.0, process_group=None, reduce_dtype=None, single_rank_ok=False):
         self.params = [p for p in params if p.requires_grad]
@@ -308,13 +341,15 @@ class GraphedStep:
     `use_graphs=False` runs the same chain eagerly (forward, segments, packs, collectives in the same order) on any device: that is what
     the 2-rank gloo test on the CPU exercises, and a debugging aid on the GPU."""
 
-    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None):
+    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None, mode="chain"):
         from . import runtime
         red = stepper.reducer
         self.red, self.stepper, self.stream = red, stepper, stream
         red.set_manual(True)
         self.side = red.side
         self.use_graphs = bool(use_graphs)
+        self.mode = mode if self.use_graphs else "chain"
+        self.comm = None
         self._forward_loss = forward_loss
         k = max(1, int(segments))
         if fractions is None:
@@ -328,6 +363,9 @@ class GraphedStep:
         # capture_error_mode "thread_local": the process group's watchdog thread polls its work events (hipEventQuery) at any time;
         # under the default global mode such a call from ANOTHER thread invalidates the capture (hipErrorStreamCaptureUnsupported)
         mode = dict(capture_error_mode="thread_local")
+        if self.mode == "single":
+            self._capture_single(stepper, forward_loss, stream, mode)
+            return
         g0 = torch.cuda.CUDAGraph()
         runtime.begin_cuts(self.fractions)
         runtime.begin_layer_groups()
@@ -345,6 +383,47 @@ class GraphedStep:
         self.gu = torch.cuda.CUDAGraph()
         with runtime.capture(self.gu, stream, pool=g0.pool(), **mode):
             stepper.update()
+        self._adopt_buckets()
+        self.check_plan_across_ranks()
+
+    def _capture_single(self, stepper, forward_loss, stream, mode):
+        """Round 4: the WHOLE data-parallel step as ONE hipGraph.  The collective of bucket s is a raw RCCL all-reduce (AbiComm) captured on the
+        reducer stream, a branch forked from the capture's origin right after segment s has packed its bucket and joined back just before the
+        optimizer: it crosses xGMI while the origin and the three encoder branches differentiate segment s+1, exactly as in the chain, but
+        without the S graph boundaries (each drained all four branches and cost a graph launch).  Legal capture topology only: every edge
+        starts or ends at the origin (runtime.stream_wait enforces it)."""
+        from . import runtime
+        red = self.red
+        if not red._cuda or red.side is None:
+            raise RuntimeError("GraphedStep(mode='single') needs the GPU reducer stream")
+        self.comm = AbiComm(red.pg, red.world, dist.get_rank(red.pg) if dist.is_initialized() else 0)
+        # RCCL sets up its channels on first use: that must not happen inside a capture
+        warm = torch.zeros(1 << 16, dtype=torch.float32, device=red.params[0].device)
+        with torch.cuda.stream(red.side):
+            self.comm.allreduce_mean(warm, red.side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        runtime.begin_cuts(self.fractions)
+        runtime.begin_layer_groups()
+        with runtime.capture(g, stream, branches=[red.side], **mode):
+            self.loss = forward_loss()
+            self.seg = SegmentedBackward(self.loss, runtime.end_cuts())
+            self.groups = runtime.end_layer_groups()
+            for s in range(self.seg.nseg):
+                self._run_and_pack(s)
+                flat = self.flats[s][1]
+                if flat is None or not red._active or _SKIP_REDUCE:
+                    continue
+                runtime.stream_wait(red.side, stream)               # fork: bucket s is packed
+                with torch.cuda.stream(red.side):
+                    buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
+                    self.comm.allreduce_mean(buf, red.side)
+                    if buf is not flat:
+                        flat.copy_(buf)
+            runtime.stream_wait(stream, red.side)                   # join: every bucket reduced
+            stepper.update()
+        self.graphs = [g]
+        self.gu = None
         self._adopt_buckets()
         self.check_plan_across_ranks()
 
@@ -477,6 +556,9 @@ class GraphedStep:
     def run(self):
         if not self.use_graphs:
             return self._run_eager()
+        if self.mode == "single":
+            self.graphs[0].replay()
+            return self.loss
         main = torch.cuda.current_stream()
         for g, (_, flat) in zip(self.graphs, self.flats):
             g.replay()
@@ -525,5 +607,8 @@ class GraphedStep:
         how = f"{len(self.graphs)} hipGraphs" if self.use_graphs else "eager chain"
         tot = sum(flat.numel() - len(pl) for pl, flat in self.flats if flat is not None)
         arena = f"; gradient arena: {100.0 * getattr(self, 'in_place', 0) / max(tot, 1):.0f} % of the bucket elements written in place by their kernels" if ARENA else ""
+        if self.mode == "single":
+            return (f"ONE hipGraph (forward, backward in {self.seg.nseg} segments, optimizer); bucket s all-reduced by a CAPTURED raw RCCL call (C ABI "
+                    f"tav_allreduce_bucket, RCCL {self.comm.version}) on the reducer branch while segment s+1 runs; buckets [{sizes}] MiB{arena}")
         return (f"{how} (forward + backward cut into {self.seg.nseg} segments) + optimizer {'graph' if self.use_graphs else 'call'}; bucket s all-reduced "
                 f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; buckets [{sizes}] MiB{arena}")

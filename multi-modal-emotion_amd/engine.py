@@ -62,6 +62,7 @@ class WeightCache:
     def __init__(self, policy):
         self.pol = policy
         self.d = {}
+        self._fp8_states = None
 
     @staticmethod
     def _same(refs, params):
@@ -149,13 +150,26 @@ class WeightCache:
         self.d[key] = (ver, val, aux, self._refs(params))
         return val
 
-    def layer_fp8(self, wq, wk, wv, bq, bk, bv, wo, w1, w2):
-        """e4m3 operands of one transformer layer (per-tensor scales): (Wqkv, Wo, W1, W2) as ops.Fp8 with both the [N, K] copy (forward) and
-        the transposed [K, N_pad] copy (dgrad), quantised from the fused bf16 operands of layer()."""
+    def fp8_state(self, param, tag):
+        """(Fp8States, key) of one quantisation site: the tensor `tag` produced next to `param` (a layer's wq identifies the layer)."""
+        if self._fp8_states is None:
+            self._fp8_states = ops.Fp8States(param.device)
+        return self._fp8_states, (id(param), tag)
+
+    def layer_fp8(self, wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=None):
+        """e4m3 operands of one transformer layer (per-tensor scales): (Wqkv forward, Wqkv dgrad, Wo, W1, W2) as ops.Fp8.  The forward Wqkv is
+        the [3H, K] copy of the q-SCALED bf16 operand (q_scale as in layer(): the attention kernels get q * scale * log2(e) from the
+        projection), the dgrad Wqkv the transposed [K, 3H_pad] copy of the UNSCALED one (the attention backward returns the gradient
+        w.r.t. the unscaled q); Wo / W1 / W2 carry both copies.  Weights move little from step to step: delayed scaling (ops.fp8_quantize)."""
         def build():
-            wqkv, _, _, wo_n, _, w1_n, _, w2_n, _ = self.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
-            return tuple(ops.fp8_quantize(w, want_t=True) for w in (wqkv, wo_n, w1_n, w2_n))
-        return self._get(("layer_fp8", id(wq)), (wq, wk, wv, wo, w1, w2), build)
+            wqkv, wqkv_t, _, wo_n, _, w1_n, _, w2_n, _ = self.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=q_scale)
+            f = ops.fp8_quantize(wqkv, want_t=False, state=self.fp8_state(wq, "Wqkv.f"))
+            # the dgrad operand is the transposed copy [K, 3H] of the UNSCALED weight: exactly the row-major e4m3 copy of layer()'s Wqkv^T
+            bq8 = ops.fp8_quantize(wqkv_t, want_t=False, state=self.fp8_state(wq, "Wqkv.b"))
+            b = ops.Fp8(None, bq8.q, bq8.scales, wqkv_t.shape[1], wqkv_t.shape[0])
+            rest = tuple(ops.fp8_quantize(w, want_t=True, state=self.fp8_state(wq, t)) for w, t in ((wo_n, "Wo"), (w1_n, "W1"), (w2_n, "W2")))
+            return (f, b) + rest
+        return self._get(("layer_fp8", id(wq), q_scale), (wq, wk, wv, wo, w1, w2), build)
 
     def conv(self, w, stride=0):
         """nn.Conv1d weight [co,ci,k] -> (operand [co, k*ci], column-buffer dgrad operand [k*ci, co], per-phase dgrad operands or None)."""
@@ -407,10 +421,11 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = params
         B, S, nh = spec.B, spec.S, spec.nheads
         H = nh * 64
-        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
-        wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        wqkv, _, bqkv, wo_n, _, w1_n, _, w2_n, _ = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
+        wqkv8, _, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
         fm = pol.fp8_fwd
         a8 = o8 = c8 = h8 = None
+        st = lambda tag: cache.fp8_state(wq, tag)           # noqa: E731  (one delayed-scaling state per quantisation site of this layer)
         x = _c(x)
         if spec.pre_ln:
             _, a, mean1, rstd1 = _ln_fwd(pol, x, ln1_w, ln1_b, spec.eps, need_f32=False)
@@ -418,13 +433,13 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
             a = x_lp if x_lp is not None else _to_lp(pol, x)
             mean1 = rstd1 = None
         if fm & 1:
-            a8 = ops.fp8_quantize(a, want_t=pol.fp8_wgrad8)
+            a8 = ops.fp8_quantize(a, want_t=pol.fp8_wgrad8, state=st("a"))
             qkv = ops.gemm_nt_fp8(a8, wqkv8, bias=bqkv)
         else:
             qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
-        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+        o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
         if fm & 2:
-            o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8)
+            o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8, state=st("o"))
             y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
         else:
             y1 = ops.gemm_nt(o, wo_n, bias=bo, resid=x, out_dtype=torch.float32)
@@ -434,12 +449,12 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         else:
             x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
         if fm & 4:
-            c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8)
+            c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8, state=st("c"))
             h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
         else:
             h, u = ops.gemm_nt(c, w1_n, bias=b1, act=3, want_pre=True)
         if fm & 8:
-            h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8)
+            h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8, state=st("h"))
             y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
         else:
             y2 = ops.gemm_nt(h, w2_n, bias=b2, resid=x1, out_dtype=torch.float32)
@@ -472,16 +487,17 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         (ln1_w, ln1_b, wq, bq, wk, bk, wv, bv, wo, bo, ln2_w, ln2_b, w1, b1, w2, b2) = sv[22:]
         B, S, nh = spec.B, spec.S, spec.nheads
         H, F, M = nh * 64, w1.shape[0], ctx.rows
-        wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2)
-        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2)
+        _, wqkv8, wo8, w18, w28 = cache.layer_fp8(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
+        _, wqkv_t, _, _, wo_t, _, w1_t, _, w2_t = cache.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=QSC)
         w8 = pol.fp8_wgrad8
         bm = pol.fp8_bwd
+        pre = QSC is not None
         if w8:
             a8, o8, c8, h8 = (ops.Fp8(None, t, s, M, t.shape[0]) for t, s in ((a_t, a_s), (o_t, o_s), (c_t, c_s), (h_t, h_s)))
 
         def dgrad(dy_lp, bit, wq8, w_t, **kw):   # dY [M, N] x W [N, K] -> [M, K]: the NT GEMM against the transposed copy W^T [K, N(_pad)]
             if bm & bit:
-                dy8 = ops.fp8_quantize(dy_lp, want_t=w8)
+                dy8 = ops.fp8_quantize(dy_lp, want_t=w8, state=cache.fp8_state(wq, f"dY{bit}"))
                 return ops.gemm_nt(dy8.q, wq8.qt[:, :wq8.rows], a_dequant=dy8.dequant, b_dequant=wq8.dequant, **kw), dy8
             return ops.gemm_nt(dy_lp, w_t, **kw), None
 
@@ -492,23 +508,23 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
             dg2 = db2 = None
         else:
             dy2, dy2_lp, dg2, db2 = _ln_bwd(pol, g2, y2, ln2_w, ln2_b, mean2, rstd2)
-        du, dy28 = dgrad(dy2_lp, 1, w28, w2_t, gelu_in=u, act=4)
+        du, dy28 = dgrad(dy2_lp, 8, w28, w2_t, gelu_in=u, act=4)
         if spec.pre_ln:
-            dc, du8 = dgrad(du, 2, w18, w1_t, out_dtype=torch.float32)
+            dc, du8 = dgrad(du, 4, w18, w1_t, out_dtype=torch.float32)
             g1, g1_lp, dg2, db2 = _ln_bwd(pol, dc, y1, ln2_w, ln2_b, mean2, rstd2, dx_add=dy2)
             dy1, dy1_lp = g1, g1_lp
         else:
-            g1, du8 = dgrad(du, 2, w18, w1_t, resid=dy2, out_dtype=torch.float32)
+            g1, du8 = dgrad(du, 4, w18, w1_t, resid=dy2, out_dtype=torch.float32)
             dy1, dy1_lp, dg1, db1 = _ln_bwd(pol, g1, y1, ln1_w, ln1_b, mean1, rstd1)
-        do, dy18 = dgrad(dy1_lp, 4, wo8, wo_t)
+        do, dy18 = dgrad(dy1_lp, 2, wo8, wo_t)
         dqkv = ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, (corr, o_soft) if spec.mask_mode == 2 else None,
-                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode)
+                            B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=pre)
         if spec.pre_ln:
-            da, dqkv8 = dgrad(dqkv, 8, wqkv8, wqkv_t, out_dtype=torch.float32)
+            da, dqkv8 = dgrad(dqkv, 1, wqkv8, wqkv_t, out_dtype=torch.float32)
             g0, g0_lp, dg1, db1 = _ln_bwd(pol, da, x, ln1_w, ln1_b, mean1, rstd1, dx_add=dy1, need_lp=_LP_HINT_ON)
             _hint_set(g0, g0_lp)
         else:
-            g0, dqkv8 = dgrad(dqkv, 8, wqkv8, wqkv_t, resid=dy1, out_dtype=torch.float32)
+            g0, dqkv8 = dgrad(dqkv, 1, wqkv8, wqkv_t, resid=dy1, out_dtype=torch.float32)
         if w8:
             dW2, dW1, dWo, dWqkv = ops.wgrad_fp8(dy28, h8), ops.wgrad_fp8(du8, c8), ops.wgrad_fp8(dy18, o8), ops.wgrad_fp8(dqkv8, a8)
             dB2, dB1, dBo, dBqkv = ops.colsum(dy2_lp), ops.colsum(du), ops.colsum(dy1_lp), ops.colsum(dqkv)

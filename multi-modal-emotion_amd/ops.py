@@ -198,16 +198,68 @@ class Fp8:
         return self.scales[1:2]
 
 
-def fp8_quantize(x, *, want_q=True, want_t=False):
-    """x [rows, cols] f32 / bf16 (row stride arbitrary) -> Fp8.  Two launches for the absolute maximum, one for the copies; the scale
-    stays on the device."""
+# Delayed scaling (round 4): a tensor that is quantised every step at the same place of the graph keeps a 4-float STATE on the device
+# (tav_fp8_quantize_delayed).  Its first quantisation calibrates (current scaling: amax passes + quantiser, what rounds 2-3 did every time);
+# from then on ONE launch quantises with the scale the previous step left and gathers the new maximum on the way; fp8_roll_all() -- called by the
+# optimizer step, inside the captured graph -- turns the gathered maxima into the next step's scales.  TAV_FP8_DELAYED=0: always current scaling.
+fp8_delayed = [os.environ.get("TAV_FP8_DELAYED", "1") == "1"]
+_fp8_state_sets = []
+
+
+class Fp8States:
+    """`n` states of 4 floats in one device tensor; slot(key) hands out (and remembers) the state of one quantisation site."""
+
+    def __init__(self, device, n=8192):
+        import weakref
+        self.dev = torch.zeros(n, 4, dtype=torch.float32, device=device)
+        self.index, self.calibrated = {}, set()
+        _fp8_state_sets.append(weakref.ref(self))
+
+    def slot(self, key):
+        i = self.index.get(key)
+        if i is None:
+            i = len(self.index)
+            if i >= self.dev.shape[0]:
+                raise RuntimeError("Fp8States: out of slots")
+            self.index[key] = i
+        return i
+
+    def roll(self):
+        if self.index:
+            check(lib().tav_fp8_roll_states(ptr(self.dev), len(self.index), stream()), "fp8_roll_states")
+
+
+def fp8_roll_all():
+    """End of a training step: every quantisation site's gathered maximum becomes its next scale (one tiny launch per state set)."""
+    live = []
+    for r in _fp8_state_sets:
+        st = r()
+        if st is not None:
+            st.roll()
+            live.append(r)
+    _fp8_state_sets[:] = live
+
+
+def fp8_quantize(x, *, want_q=True, want_t=False, state=None):
+    """x [rows, cols] f32 / bf16 (row stride arbitrary) -> Fp8.  Without `state`: current scaling (two launches for the absolute maximum, one for
+    the copies).  state = (Fp8States, key): delayed scaling once the site is calibrated (see above).  The scale stays on the device either way."""
     rows, cols = x.shape
-    scales = torch.empty(3, dtype=torch.float32, device=x.device)
-    part = workspace("fp8_amax", lib().tav_fp8_amax_partials(rows, cols), x.device)
-    check(lib().tav_fp8_amax(ptr(x), dt(x), rows, cols, x.stride(0), ptr(part), ptr(scales), stream()), "fp8_amax")
     q = torch.empty(rows, cols, dtype=FP8, device=x.device) if want_q else None
     rows_pad = (rows + FP8_KPAD - 1) // FP8_KPAD * FP8_KPAD
     qt = torch.empty(cols, rows_pad, dtype=FP8, device=x.device) if want_t else None
+    if state is not None:
+        sts, key = state
+        i = sts.slot(key)
+        scales = sts.dev[i]
+        if fp8_delayed[0] and i in sts.calibrated:
+            check(lib().tav_fp8_quantize_delayed(ptr(x), dt(x), rows, cols, x.stride(0), ptr(scales), ptr(q), cols, ptr(qt), rows_pad, rows_pad, stream()),
+                  "fp8_quantize_delayed")
+            return Fp8(q, qt, scales, rows, cols)
+        sts.calibrated.add(i)
+    else:
+        scales = torch.empty(3, dtype=torch.float32, device=x.device)
+    part = workspace("fp8_amax", lib().tav_fp8_amax_partials(rows, cols), x.device)
+    check(lib().tav_fp8_amax(ptr(x), dt(x), rows, cols, x.stride(0), ptr(part), ptr(scales), stream()), "fp8_amax")
     check(lib().tav_fp8_quantize(ptr(x), dt(x), rows, cols, x.stride(0), ptr(scales), ptr(q), cols, ptr(qt), rows_pad, rows_pad, stream()), "fp8_quantize")
     return Fp8(q, qt, scales, rows, cols)
 

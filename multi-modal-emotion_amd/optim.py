@@ -5,7 +5,7 @@ import ctypes as C
 
 import torch
 
-from . import engine
+from . import engine, ops
 from ._lib import check, lib, ptr, stream
 
 
@@ -139,6 +139,7 @@ class FusedAdamW:
                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, ptr(self._step_dev), ptr(self._scal[5:7]), stream()),
               "adamw_chunked")
         engine.bump_weight_epoch()          # parameters changed through raw pointers: refresh cached operand copies
+        ops.fp8_roll_all()                  # fp8 policy: this step's gathered maxima become the next step's quantisation scales (no-op otherwise)
         return self.last_norm
 
     def step(self):

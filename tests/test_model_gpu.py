@@ -737,8 +737,11 @@ def test_collate_device_feeds_captured_step(gpu):
     assert torch.equal(g_replayed, model.linear1.weight.grad)
 
 
-def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
-    """bench.py's data-parallel step (ddp.GraphedStep: forward + backward cut into segments, one hipGraph each, the bucket all-reduces issued
+@pytest.mark.parametrize("mode", ["chain", "single"])
+def test_graphed_ddp_step_single_rank(gpu, monkeypatch, mode):
+    """mode "single" (round 4): the same step as ONE hipGraph, the bucket all-reduces captured as raw RCCL calls through the C ABI on the reducer
+    branch -- same assertions.  mode "chain":
+    bench.py's data-parallel step (ddp.GraphedStep: forward + backward cut into segments, one hipGraph each, the bucket all-reduces issued
     eagerly on the reducer stream in between, optimizer graph last) on the real RCCL backend with ONE rank.  Learning rate 0 keeps the weights
     fixed, so every replay must reproduce the plain eager step bit for bit: same loss, and every gradient -- read back from the packed,
     all-reduced buckets the optimizer graph consumes -- equal to the plain backward's; the optimizer graph itself must have run (step counter)."""
@@ -782,8 +785,8 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
             torch.cuda.synchronize()
             engine.bump_weight_epoch()
             st.opt.zero_grad()
-            g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4)
-            assert g.seg.nseg == 3 and len(g.graphs) == 3          # 4-layer stacks are cut before layers 1 and 3
+            g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4, mode=mode)
+            assert g.seg.nseg == 3 and len(g.graphs) == (3 if mode == "chain" else 1)          # 4-layer stacks are cut before layers 1 and 3
             assert sum(len(pl) for pl, _ in g.flats) == len(st.opt.state)          # every trained parameter sits in exactly one bucket
             steps0 = st.opt.step_count
             losses = [g.run().item() for _ in range(3)]            # (the capture itself executed nothing)
@@ -799,6 +802,8 @@ def test_graphed_ddp_step_single_rank(gpu, monkeypatch):
                     assert torch.equal(got, ref[index[id(p)]]), f"gradient of parameter #{index[id(p)]} differs"
                     n_cmp += 1
             st.reducer.remove()
+            if g.comm is not None:
+                g.comm.destroy()
     finally:
         if created:
             dist.destroy_process_group()
@@ -872,6 +877,64 @@ def test_config5_parity_vs_oracle(gpu, policy, tol):
     print(f"[config 5, {policy}] logits {e[0]:.2e} loss {e[1]:.2e} grad-norm {e[2]:.2e} worst tensor {worst:.2e} ({worst_k})")
     assert max(e) < tol, e
     assert worst < {"fp32": 1e-3, "bf16": 3e-2, "fp8": 0.15, "fp8-all": 0.3}[policy], (worst, worst_k)
+
+
+def test_fp8_delayed_scaling_equals_its_calibration_pass(gpu):
+    """Round 4, fp8 policy: the first pass over a quantisation site calibrates (amax passes + quantiser, current scaling); every later pass is ONE
+    launch that quantises with the scale the previous step left and gathers the new maximum (tav_fp8_quantize_delayed), rolled by the optimizer
+    step (tav_fp8_roll_states).  With weights and inputs unchanged the maxima are unchanged, so passes 2 and 3 -- delayed, with a roll in between --
+    must reproduce the calibration pass bit for bit (logits and every gradient); and a tensor that GREW past last step's maximum saturates
+    instead of overflowing."""
+    from tav_amd import ops
+    cfg = C.preset("B5")
+    for k in ("text", "audio", "video", "fusion"):
+        cfg[k]["layers"] = 2
+    cfg["text"]["vocab"] = 1000
+    cfg["video"]["image"] = 64
+    runtime.set_precision("fp8")
+    torch.manual_seed(0)
+    pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+    synthetic.seeded_init_(pre, 1)
+    synthetic.seeded_init_(model, 2)
+    nvt = 16
+    (tx, au, vi), lab = synthetic.make_batch(cfg, 2, s_text=32, t_audio=16000, n_visual_true=nvt)
+    batch = _as_batch(tx, au, vi)
+    pre.cuda()
+    model.cuda()
+    params = list(pre.parameters()) + list(model.parameters())
+
+    def one_pass():
+        for p in params:
+            p.grad = None
+        _, _, _, logits, loss = _run_product(pre, model, batch, lab)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in params]
+
+    sts = runtime.ctx().cache._fp8_states
+    assert sts is None or not sts.calibrated
+    l0, g0 = one_pass()                                   # calibrates every site
+    sts = runtime.ctx().cache._fp8_states
+    assert sts is not None and len(sts.calibrated) == len(sts.index) >= 2 * (1 + 4 + 5)      # per video layer: a, four dY, five weight operands
+    assert float(sts.dev[:len(sts.index), 3].abs().max()) == 0.0                              # (calibration gathers nothing)
+    l1, g1 = one_pass()                                   # delayed, scales of the calibration pass
+    assert float(sts.dev[:len(sts.index), 3].max()) > 0.0                                     # the delayed kernels gathered their maxima
+    ops.fp8_roll_all()
+    torch.cuda.synchronize()
+    assert float(sts.dev[:len(sts.index), 3].abs().max()) == 0.0
+    l2, g2 = one_pass()                                   # delayed, scales rolled from pass 2's maxima (= the same maxima)
+    for lg, gg in ((l1, g1), (l2, g2)):
+        assert torch.equal(lg, l0)
+        assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(gg, g0))
+    # saturation: quantise a tensor 8x larger than the state's maximum with the stale scale
+    x = torch.randn(256, 512, device="cuda").bfloat16()
+    key = (sts, ("probe", "x"))
+    a = ops.fp8_quantize(x, state=key)                    # calibrates
+    b = ops.fp8_quantize((x.float() * 8).bfloat16(), state=key)      # delayed, scale too large by 8x
+    torch.cuda.synchronize()
+    qa, qb = a.q.float(), b.q.float()
+    assert torch.isfinite(qb).all() and float(qb.abs().max()) == 448.0 and float(qa.abs().max()) == 448.0
+    runtime.set_precision("bf16")
 
 
 def test_c_abi_allreduce_bucket_single_rank(gpu):
