@@ -61,7 +61,7 @@ def fwd_gflop_per_utt(cfg, s_text=128, t_audio=80000):
     return (pre + model) / 1e9, n_fus
 
 GLOBAL_BATCH = 32                      # BASELINE.json metric: "... b=32, 1/2/4/8 MI355X"
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc", "traffic_per_launch.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc", "traffic_per_launch.json")
 HBM_PEAK_GBS = 8000.0                 # HBM3E, same guide (about 6300 GB/s is what a streaming copy reaches)
 
 
@@ -69,13 +69,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def kernel_source_hash():
-    """Identity of the code the PMC traffic figure was taken on: the GEMM kernel sources (there is no .git on the GPU box)."""
+def kernel_source_hash(files=("gemm.hip", "common.h")):
+    """Identity of the code a PMC traffic figure was taken on: the kernel sources of that family (there is no .git on the GPU box)."""
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in files:
         with open(os.path.join(ROOT, "multi-modal-emotion_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+FAMILY_SOURCES = {"attention": ("attention.hip", "common.h"), "layernorm": ("norm.hip", "common.h"), "gemm_tn": ("gemm.hip", "common.h")}
+FAMILY_KERNELS = {"attention": ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"), "layernorm": ("ln_fwd_kernel", "ln_bwd_kernel"),
+                  "gemm_tn": ("gemm_tn_grouped_big_kernel", "gemm_tn_grouped_kernel", "gemm_tn_kernel")}
 
 
 def parse_args():
@@ -96,6 +101,8 @@ def parse_args():
                     help="bounded: b=1, 2 warm-ups, median of 5 (~25 s); full: BASELINE.md §3, b in {1, 8} (several minutes)")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
+    ap.add_argument("--reduce-bf16-tail", action="store_true", help="N > 1: only the LAST bucket (lowest segment: front-ends, embedding tables -- the one "
+                    "all-reduce nothing is left to hide behind) crosses xGMI in bf16; every other gradient stays f32 on the wire")
     ap.add_argument("--graph", type=int, default=1, help="1: capture the step into hipGraphs and replay them; 0: eager launches (debugging)")
     ap.add_argument("--profile-serial", action="store_true",
                     help="profiling mode: eager launches, every branch on ONE stream, so that a rocprofv3 --kernel-trace --stats of this command sees each "
@@ -323,9 +330,9 @@ def main():
             fwd = lambda: stepper.forward_loss(inp, labels, check="val", epoch=0, n_visual_true=n_true)      # noqa: E731
             gstep = None
             if args.ddp_mode == "single":
-                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="single")
+                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="single", tail_bf16=args.reduce_bf16_tail)
             if gstep is None:
-                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="chain")
+                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="chain", tail_bf16=args.reduce_bf16_tail)
         except Exception as e:
             capture_failed(e)
         graph, one_step = gstep, gstep.run
@@ -522,6 +529,18 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(getattr(ops.profile_stop, "algorithmic_bytes", 0.0) / max(launches, 1)), "launches_per_step": launches // 2,
                 "avg_launch_us": round(secs / launches * 1e6, 2), "serial_ms_per_step": round(secs / 2 * 1e3, 3)}
+        # HBM traffic of the other families' kernels from the same committed PMC passes (bytes per launch of each kernel, averaged over every launch of
+        # the replayed steps: all four stacks' shapes), valid while THAT family's sources are the ones that were profiled
+        try:
+            for fam, f_ in fams.items():
+                want = kernel_source_hash(FAMILY_SOURCES[fam])
+                ok = rec.get("family_source_hashes", {}).get(fam) == want and rec.get("per_gpu_batch") == b and rec.get("preset") == args.preset
+                f_["traffic"] = ({k: rec["families"][k]["hbm_bytes_per_launch_corrected"] for k in FAMILY_KERNELS[fam] if k in rec["families"]} if ok else None)
+                f_["traffic_source"] = (f"recorded: {os.path.relpath(PMC_SUMMARY, ROOT)} (bytes per kernel launch; sources {want})" if ok else
+                                        f"stale or absent: {os.path.relpath(PMC_SUMMARY, ROOT)} has {rec.get('family_source_hashes', {}).get(fam)} / batch "
+                                        f"{rec.get('per_gpu_batch')}, now {want} / {b}")
+        except Exception:
+            pass
         if fams:
             roof["families"] = fams
 

@@ -8,7 +8,8 @@
 //                     zeros to rows_pad: the weight-gradient dW = dY^T X is then the same NT GEMM (K = tokens) as every other product,
 //                     so one fp8 kernel serves forward, dgrad and wgrad
 //   tav_splitk_reduce out = sum_s slabs[s]   (the token axis of a wgrad is split over workgroups; fixed order, no atomics)
-// v_cvt_pk_fp8_f32 rounds to nearest even and saturates to +-448 (OCP e4m3fn on gfx950; MI300's fnuz encoding is not used anywhere).
+// v_cvt_pk_fp8_f32 rounds to nearest even (OCP e4m3fn on gfx950; MI300's fnuz encoding is not used anywhere); saturation to +-448 is done in
+// software (pack4_fp8): the instruction turns out-of-range inputs into NaN.
 #include "common.h"
 #include "tavhip_internal.h"
 
@@ -49,6 +50,10 @@ __global__ __launch_bounds__(256) void fp8_amax_final_kernel(const float* __rest
 }
 
 TAV_DEV uint32_t pack4_fp8(f32x4 v) {
+    // clamp first: v_cvt_pk_fp8_f32 does NOT saturate on this target as configured (measured round 4: an input beyond +-448 converts to NaN, 0x7f),
+    // and under delayed scaling a tensor may outgrow the maximum its scale was made from
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], -FP8_MAX, FP8_MAX);
     int w = 0;
     w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);

@@ -341,7 +341,7 @@ class GraphedStep:
     `use_graphs=False` runs the same chain eagerly (forward, segments, packs, collectives in the same order) on any device: that is what
     the 2-rank gloo test on the CPU exercises, and a debugging aid on the GPU."""
 
-    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None, mode="chain"):
+    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None, mode="chain", tail_bf16=False):
         from . import runtime
         red = stepper.reducer
         self.red, self.stepper, self.stream = red, stepper, stream
@@ -350,6 +350,7 @@ class GraphedStep:
         self.use_graphs = bool(use_graphs)
         self.mode = mode if self.use_graphs else "chain"
         self.comm = None
+        self.tail_bf16 = bool(tail_bf16)
         self._forward_loss = forward_loss
         k = max(1, int(segments))
         if fractions is None:
@@ -416,7 +417,8 @@ class GraphedStep:
                     continue
                 runtime.stream_wait(red.side, stream)               # fork: bucket s is packed
                 with torch.cuda.stream(red.side):
-                    buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
+                    wd = red.reduce_dtype if red.reduce_dtype is not None else (torch.bfloat16 if (self.tail_bf16 and s == self.seg.nseg - 1) else None)
+                    buf = flat if wd is None else flat.to(wd)
                     self.comm.allreduce_mean(buf, red.side)
                     if buf is not flat:
                         flat.copy_(buf)
@@ -542,11 +544,21 @@ class GraphedStep:
             raise RuntimeError("data-parallel bucket plans differ across ranks (rank: [(parameters, elements) per bucket]): "
                                + "; ".join(f"{r}: {p}" for r, p in enumerate(plans)))
 
-    def _reduce(self, flat):
+    def _wire_dtype(self, s):
+        """Wire format of bucket s: the reducer's reduce_dtype, or -- `tail_bf16` -- bf16 for the LAST bucket only: the lowest segment (first
+        layers, front-ends, the two 94 MB embedding tables, PreFormer) is the one all-reduce with no backward left to hide behind, so
+        halving ITS bytes halves the exposed tail while every other gradient still travels in f32."""
+        red = self.red
+        if red.reduce_dtype is not None:
+            return red.reduce_dtype
+        return torch.bfloat16 if (self.tail_bf16 and s == self.seg.nseg - 1) else None
+
+    def _reduce(self, flat, s=None):
         red = self.red
         if flat is None or not red._active or _SKIP_REDUCE:
             return
-        buf = flat if red.reduce_dtype is None else flat.to(red.reduce_dtype)
+        wd = self._wire_dtype(s) if s is not None else red.reduce_dtype
+        buf = flat if wd is None else flat.to(wd)
         dist.all_reduce(buf, op=dist.ReduceOp.AVG if red._avg else dist.ReduceOp.SUM, group=red.pg)
         if buf is not flat:
             flat.copy_(buf)
@@ -560,11 +572,11 @@ class GraphedStep:
             self.graphs[0].replay()
             return self.loss
         main = torch.cuda.current_stream()
-        for g, (_, flat) in zip(self.graphs, self.flats):
+        for s, (g, (_, flat)) in enumerate(zip(self.graphs, self.flats)):
             g.replay()
             _rt().stream_wait(self.side, main)                  # bucket s is packed: ship it while the next graph runs
             with torch.cuda.stream(self.side):
-                self._reduce(flat)
+                self._reduce(flat, s)
         _rt().stream_wait(main, self.side)
         self.gu.replay()
         return self.loss
@@ -587,9 +599,9 @@ class GraphedStep:
             if cuda:
                 _rt().stream_wait(self.side, torch.cuda.current_stream())
                 with torch.cuda.stream(self.side):
-                    self._reduce(flat)
+                    self._reduce(flat, s)
             else:
-                self._reduce(flat)
+                self._reduce(flat, s)
         if cuda:
             _rt().stream_wait(torch.cuda.current_stream(), self.side)
         sig = self.bucket_signature()

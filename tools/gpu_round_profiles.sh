@@ -7,8 +7,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 TAV_DDP_SINGLE_RANK=1 timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/bench_ddp1.json 2> gpurun_out/bench_ddp1.err
 echo "ddp single-rank bench exit $?"; tail -n 1 gpurun_out/bench_ddp1.json | cut -c1-700; grep "hipGraphs\|timed region\|rror" gpurun_out/bench_ddp1.err | head -5
-STEPS=3 tools/gpu_prof.sh r03_b32_serial --profile-serial | head -40
-STEPS=5 tools/gpu_prof.sh r03_b32_default | head -12
+STEPS=3 tools/gpu_prof.sh r04_b32_serial --profile-serial | head -40
+STEPS=5 tools/gpu_prof.sh r04_b32_default | head -12
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > gpurun_out/pmc_$c.log 2>&1 || { echo "pmc pass $c failed"; tail -n 5 gpurun_out/pmc_$c.log; exit 1; }
 done

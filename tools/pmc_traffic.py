@@ -54,12 +54,15 @@ def read(dirname, counter, steps_in_trace=1, skip_steps=0):
     return tot, cnt
 
 
-def source_hash():
+def source_hash(files=("gemm.hip", "common.h")):
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in files:
         with open(os.path.join(ROOT, "multi-modal-emotion_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+FAMILY_SOURCES = {"attention": ("attention.hip", "common.h"), "layernorm": ("norm.hip", "common.h"), "gemm_tn": ("gemm.hip", "common.h")}      # as in bench.py
 
 
 def main():
@@ -91,7 +94,7 @@ def main():
     rec = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) over `python3 bench.py --steps 2 --warmup 1 "
                    "--no-cpu-baseline --no-roofline --no-secondary`; the eager warm-up step is dropped (first 1/5 of every family's dispatches): KiB per launch "
                    "averaged over the REPLAYED steps only; raw per-dispatch CSVs beside this file (*.csv.gz); corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 counts 64 B per 128-B read request, MI355X_MICROARCH.md)",
-           "kernel_source_hash": source_hash(), "head": head, "preset": a.preset, "per_gpu_batch": a.batch, "families": fams}
+           "kernel_source_hash": source_hash(), "family_source_hashes": {k: source_hash(v) for k, v in FAMILY_SOURCES.items()}, "head": head, "preset": a.preset, "per_gpu_batch": a.batch, "families": fams}
     with open(a.out, "w") as f:
         json.dump(rec, f, indent=1)
     for k, v in fams.items():
