@@ -408,6 +408,20 @@ class EncoderLayerFn(torch.autograd.Function):
         return (g0, None, None, None, None, *grads)
 
 
+# Experiment hook (tools/gpu_fp8_mx_probe.py; never set in the product): TAV_FP8_MX_EMULATE=1 runs the forward GEMMs selected by Policy.fp8_fwd bits
+# 1-3 (out-proj / FFN1 / FFN2) on operands rounded to MX-e4m3 -- e4m3 elements with a power-of-two scale per 32 k-values, the format the
+# block-scaled MFMA takes natively -- by quantise / dequantise in torch, to measure what block scales would buy BEFORE building that path.
+_MX_EMULATE = os.environ.get("TAV_FP8_MX_EMULATE", "0") == "1"
+
+
+def _mx_roundtrip(x, block=32):
+    M, K = x.shape
+    xb = x.float().reshape(M, K // block, block)
+    amax = xb.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    sc = torch.exp2(torch.floor(torch.log2(448.0 / amax)))           # E8M0: the largest power of two that keeps the block inside +-448
+    return ((xb * sc).to(torch.float8_e4m3fn).float() / sc).reshape(M, K).to(x.dtype)
+
+
 class EncoderLayerFp8Fn(torch.autograd.Function):
     """EncoderLayerFn with the four linear layers on e4m3 operands (Policy("fp8"), BASELINE config 5).  Each GEMM input (LayerNorm output,
     attention output, GELU output, and in the backward the four incoming gradients) is quantised once per use with its own per-tensor
@@ -438,7 +452,9 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
         else:
             qkv = ops.gemm_nt(a, wqkv, bias=bqkv)
         o, lse, aux = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nh, key_mask=key_mask, mask_mode=spec.mask_mode, q_prescaled=QSC is not None)
-        if fm & 2:
+        if (fm & 2) and _MX_EMULATE:
+            y1 = ops.gemm_nt(_mx_roundtrip(o), _mx_roundtrip(wo_n), bias=bo, resid=x, out_dtype=torch.float32)
+        elif fm & 2:
             o8 = ops.fp8_quantize(o, want_t=pol.fp8_wgrad8, state=st("o"))
             y1 = ops.gemm_nt_fp8(o8, wo8, bias=bo, resid=x, out_dtype=torch.float32)
         else:
@@ -448,12 +464,16 @@ class EncoderLayerFp8Fn(torch.autograd.Function):
             _, c, mean2, rstd2 = _ln_fwd(pol, x1, ln2_w, ln2_b, spec.eps, need_f32=False)
         else:
             x1, c, mean1, rstd1 = _ln_fwd(pol, y1, ln1_w, ln1_b, spec.eps, need_f32=True)
-        if fm & 4:
+        if (fm & 4) and _MX_EMULATE:
+            h, u = ops.gemm_nt(_mx_roundtrip(c), _mx_roundtrip(w1_n), bias=b1, act=3, want_pre=True)
+        elif fm & 4:
             c8 = ops.fp8_quantize(c, want_t=pol.fp8_wgrad8, state=st("c"))
             h, u = ops.gemm_nt_fp8(c8, w18, bias=b1, act=3, want_pre=True)
         else:
             h, u = ops.gemm_nt(c, w1_n, bias=b1, act=3, want_pre=True)
-        if fm & 8:
+        if (fm & 8) and _MX_EMULATE:
+            y2 = ops.gemm_nt(_mx_roundtrip(h), _mx_roundtrip(w2_n), bias=b2, resid=x1, out_dtype=torch.float32)
+        elif fm & 8:
             h8 = ops.fp8_quantize(h, want_t=pol.fp8_wgrad8, state=st("h"))
             y2 = ops.gemm_nt_fp8(h8, w28, bias=b2, resid=x1, out_dtype=torch.float32)
         else:
