@@ -65,34 +65,49 @@ class PreFormer(nn.Module):
         # synchronises the host and cannot be captured into a hipGraph
         return torch.arange(feature_vector_length, device=attention_mask.device)[None, :] < out_len[:, None]
 
-    def _mask_hidden_states(self, hidden, B, T, attention_mask, training=False):
-        """SpecAugment along time (reference models/tav.py:269-306 -> HF _compute_mask_indices, wav2vec2:101): per row, `n` spans of
-        mask_time_length frames, n = max(int(mask_time_prob * len / mask_time_length + eps), min_masks) with eps ~ U[0,1), starts drawn without
-        replacement from the row's valid range, the masked frames replaced by `masked_spec_embed`.  The reference samples on the host with
-        numpy; here the same distribution is drawn ON THE DEVICE (torch ops only, no host read), so a training step with train=True stays
-        graph-capturable.  The number of spans a row can take is bounded by the static sequence length; surplus slots are switched off by
-        comparison instead of by shape.  Only active when train=True, which is outside the parity / benchmark configuration."""
-        mask_prob, mask_len, min_masks = 0.05, 10, 2        # Wav2Vec2Config defaults (mask_time_prob / mask_time_length), min_masks as in the reference
-        if not training or T < mask_len:
-            return hidden
-        dev = hidden.device
-        if attention_mask is not None:
-            lens = attention_mask.to(dev).sum(-1).to(torch.float32)                         # frames that are not padding, per row
-        else:
-            lens = torch.full((B,), float(T), device=dev)
-        eps = torch.rand(1, device=dev).expand(B)                                               # ONE epsilon per call, as _compute_mask_indices draws it
-        n = torch.clamp((mask_prob * lens / mask_len + eps).floor(), min=float(min_masks))
-        n = torch.minimum(n, torch.clamp(((lens - (mask_len - 1)) / 1.0).floor(), min=0.0))  # never more spans than start positions
-        n = torch.minimum(n, torch.full_like(n, float(T // mask_len)))
-        max_spans = max(min_masks, int(mask_prob * T / mask_len + 1.0))                      # static bound (eps < 1)
-        pos = torch.arange(T, device=dev)[None, :]
-        score = torch.rand(B, T, device=dev)
-        score = torch.where(pos < (lens[:, None] - (mask_len - 1)), score, torch.full_like(score, 2.0))   # starts outside the valid range sort last
+    @staticmethod
+    def _span_mask(B, L, lens, prob, length, min_masks, dev):
+        """bool [B, L]: per row n spans of `length` positions, n = max(int(prob * len / length + eps), min_masks) with ONE eps ~ U[0,1) per call,
+        starts drawn without replacement from the row's valid range [0, len - length] -- HF `_compute_mask_indices` (wav2vec2:101), the
+        reference's sampler (models/tav.py:283-289, :296-301), drawn with torch ops on the device (no host read: capturable).  The number of spans a
+        row can take is bounded by the static L; surplus slots are switched off by comparison instead of by shape."""
+        eps = torch.rand(1, device=dev).expand(B)
+        n = torch.clamp((prob * lens / length + eps).floor(), min=float(min_masks))
+        n = torch.minimum(n, torch.clamp((lens - (length - 1)).floor(), min=0.0))           # never more spans than start positions
+        n = torch.minimum(n, torch.full_like(n, float(L // length)))
+        max_spans = max(int(min_masks), int(prob * L / length + 1.0), 1)                     # static bound (eps < 1)
+        pos = torch.arange(L, device=dev)[None, :]
+        score = torch.rand(B, L, device=dev)
+        score = torch.where(pos < (lens[:, None] - (length - 1)), score, torch.full_like(score, 2.0))   # starts outside the valid range sort last
         starts = score.argsort(dim=1)[:, :max_spans]                                          # without replacement
         live = torch.arange(max_spans, device=dev)[None, :] < n[:, None]
-        cover = (pos[:, None, :] >= starts[:, :, None]) & (pos[:, None, :] < starts[:, :, None] + mask_len) & live[:, :, None]
-        sel = cover.any(dim=1).reshape(B * T, 1)
-        return torch.where(sel, self.masked_spec_embed.to(hidden.dtype)[None, :], hidden)
+        cover = (pos[:, None, :] >= starts[:, :, None]) & (pos[:, None, :] < starts[:, :, None] + length) & live[:, :, None]
+        return cover.any(dim=1)
+
+    def _mask_hidden_states(self, hidden, B, T, attention_mask, training=False):
+        """SpecAugment (reference models/tav.py:269-306).  Along TIME (:281-290): spans of mask_time_length frames inside each row's valid range are
+        replaced by `masked_spec_embed`; along the FEATURE axis (:292-304, round 4): spans of mask_feature_length channels are zeroed for every
+        frame of the row -- inactive under the Wav2Vec2Config default mask_feature_prob = 0, which is what the reference's checkpoint carries.
+        The reference samples on the host with numpy; here the same distribution is drawn ON THE DEVICE (`_span_mask`), so a training step with
+        train=True stays graph-capturable.  Only active when train=True, which is outside the parity / benchmark configuration."""
+        ac = self.cfg["audio"] if hasattr(self, "cfg") else {}
+        mask_prob, mask_len, min_masks = ac.get("mask_time_prob", 0.05), ac.get("mask_time_length", 10), ac.get("mask_time_min_masks", 2)   # Wav2Vec2Config defaults; min_masks as the reference passes it
+        f_prob, f_len, f_min = ac.get("mask_feature_prob", 0.0), ac.get("mask_feature_length", 10), ac.get("mask_feature_min_masks", 0)
+        if not training or T < mask_len:                                                       # (:277-278)
+            return hidden
+        dev = hidden.device
+        if mask_prob > 0:
+            if attention_mask is not None:
+                lens = attention_mask.to(dev).sum(-1).to(torch.float32)                       # frames that are not padding, per row
+            else:
+                lens = torch.full((B,), float(T), device=dev)
+            sel = self._span_mask(B, T, lens, mask_prob, mask_len, min_masks, dev).reshape(B * T, 1)
+            hidden = torch.where(sel, self.masked_spec_embed.to(hidden.dtype)[None, :], hidden)
+        if f_prob > 0:
+            Hh = hidden.shape[1]
+            fsel = self._span_mask(B, Hh, torch.full((B,), float(Hh), device=dev), f_prob, f_len, f_min, dev)      # [B, H]: no attention mask on this axis (:296-301)
+            hidden = torch.where(fsel[:, None, :].expand(B, T, Hh).reshape(B * T, Hh), torch.zeros((), dtype=hidden.dtype, device=dev), hidden)
+        return hidden
 
     def forward(self, input_ids=None, audio_features=None, video_embeds=None, text_mask=None, audio_mask=None, visual_mask=None,
                 device="cpu", train=False, n_visual_true=None):

@@ -557,6 +557,18 @@ def test_specaugment_distribution_matches_hf_compute_mask_indices():
     ours, hf = ours / trials, hf / trials
     assert torch.allclose(ours, hf, rtol=0.08), (ours, hf)
     assert (pre._mask_hidden_states(torch.zeros(B * T, Ha), B, T, amask, training=False) == 0).all()      # train=False: untouched
+    # feature axis (reference :292-304; off under the default mask_feature_prob = 0): spans of channels zeroed for EVERY frame of a row
+    Hf = 64
+    pre.masked_spec_embed = torch.nn.Parameter(torch.full((Hf,), 7.0))
+    pre.cfg = {"audio": {"mask_time_prob": 0.0, "mask_feature_prob": 0.2, "mask_feature_length": 4, "mask_feature_min_masks": 1}}
+    ours_f, hf_f = 0.0, 0.0
+    for _ in range(200):
+        out = pre._mask_hidden_states(torch.ones(B * T, Hf), B, T, amask, training=True).view(B, T, Hf)
+        z = out == 0
+        assert torch.equal(z, z[:, :1, :].expand_as(z))           # the same channels on every frame of a row
+        ours_f += z[:, 0, :].float().sum(1).mean().item()
+        hf_f += float(_compute_mask_indices((B, Hf), mask_prob=0.2, mask_length=4, min_masks=1).sum(1).mean())
+    assert abs(ours_f - hf_f) / hf_f < 0.08, (ours_f, hf_f)
 
 
 def test_emitted_isa_discipline():
@@ -569,6 +581,8 @@ def test_emitted_isa_discipline():
     spec.loader.exec_module(ci)
     if not os.path.exists(ci.OBJDUMP):
         pytest.skip("llvm-objdump not available")
+    if not os.path.exists(os.path.join(ROOT, "multi-modal-emotion_amd", "libtavhip.so")):
+        pytest.skip("libtavhip.so has not been built (python -c 'import __graft_entry__ as g; g.build()')")
     problems, stats = ci.check(os.path.join(ROOT, "multi-modal-emotion_amd", "libtavhip.so"))
     assert stats["lds_dma"] > 1000 and stats["readfirstlane"] > 100 and stats["m0_writes"] >= stats["lds_dma"]
     assert not problems, problems[:5]
@@ -586,9 +600,10 @@ def test_emitted_isa_discipline():
     assert ci.check_text([("good", good)])[0] == []
     bad_m0 = good.replace("\ts_nop 0\n\tglobal_load_lds", "\tglobal_load_lds")                       # no wait state between the M0 write and the DMA
     bad_user = good + "\ts_movrels_b32 s1, s2\n"                                                     # a compiler-made M0 user
+    bad_idx = good + "\ts_set_gpr_idx_on s4, 0x1\n"                                                  # gfx9 VGPR indexing: uses M0 without naming it
     bad_lane = good.replace("\ts_nop 1\n\tv_readfirstlane", "\tv_readfirstlane")                     # VALU write -> lane read, no wait state
     bad_vmem = good.replace("\ts_nop 4\n", "\ts_nop 1\n")                                            # VMEM reads the SGPR 2 wait states later
-    for txt in (bad_m0, bad_user, bad_lane, bad_vmem):
+    for txt in (bad_m0, bad_user, bad_idx, bad_lane, bad_vmem):
         assert ci.check_text([("bad", txt)])[0], txt
 
 

@@ -4,12 +4,13 @@ suite calls it (tests/test_abi_and_host.py::test_emitted_isa_discipline) and `__
     python tools/check_isa.py [path/to/libtavhip.so]
 
 hipcc neither pads hazards inside inline asm nor knows what an asm statement does to M0, so two hand-maintained invariants of csrc/common.h
-are verified on the binary itself:
+are verified on the binary itself.  (Declaring "m0" as a clobber of glds16_m0 is not an alternative: hipcc 7.2 answers `inline asm clobber list
+contains reserved registers: m0 ... may lead to undefined behaviour` -- M0 is not allocatable, there is nothing for the compiler to keep out of it.)
 
  1. M0 discipline (glds16_s / glds16_m0 / glds16_x4).  The GEMM main loops write M0 WITHOUT saving it.  That is only legal while nothing the
     compiler generates uses M0.  Checked: every instruction that names m0 is `s_mov_b32 m0, x`, `s_add_u32 m0, x, y` or `s_mov_b32 sN, m0`;
     every M0 write is followed -- over at most one s_nop -- by a global_load_lds_dwordx4, or is the restore that directly follows one; and no
-    other implicit M0 user (ds_gws*, s_sendmsg*, *movrel*, v_interp*, ds_*addtid*, buffer_load ... lds) exists in the library.
+    other implicit M0 user (ds_gws*, s_sendmsg*, *movrel*, v_interp*, ds_*addtid*, s_set_gpr_idx*, buffer_load ... lds) exists in the library.
 
  2. to_sgpr (opaque v_readfirstlane_b32 with hand-placed s_nops; round 2 lost a day to this one).  For EVERY v_readfirstlane_b32 sX, vY
     in the library, compiler-made ones included: the instruction in front of it does not write vY (VALU write -> lane read needs one wait
@@ -26,7 +27,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-M0_IMPLICIT = re.compile(r"^(ds_gws|s_sendmsg|s_movrel|v_movrel|v_interp|ds_\w*addtid|s_ttrace)")
+M0_IMPLICIT = re.compile(r"^(ds_gws|s_sendmsg|s_movrel|v_movrel|v_interp|ds_\w*addtid|s_ttrace|s_set_gpr_idx)")     # (s_set_gpr_idx_on/off/idx: gfx9 VGPR indexing writes and uses M0 without naming it)
 INST = re.compile(r"^\s*([a-z_0-9]+)\s*(.*?)\s*(?://.*)?$")
 
 
