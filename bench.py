@@ -23,6 +23,7 @@ A failed hipGraph capture is fatal (exit code 3): an eager fallback would silent
 import argparse
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -379,6 +380,15 @@ def main():
     final_loss = loss.item()
     log(f"[rank {rank}] host enqueue {host_enqueue / args.steps * 1e3:.2f} ms/step vs wall {elapsed / args.steps * 1e3:.2f} ms/step")
     log(f"[rank {rank}] timed region: {elapsed / args.steps * 1e3:.2f} ms/step, loss {final_loss:.5f}")
+    # A non-finite loss means the timed steps computed garbage (round 4: an fp8 overflow turned the activations into NaN, and kernels fed NaN ran
+    # FASTER -- comparisons false, branches skipped, atomics skipped -- which produced a flattering, invalid number).  Never report such a run.
+    bad = torch.tensor([0.0 if math.isfinite(final_loss) else 1.0], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+    if bad.item() > 0:
+        log(f"[rank {rank}] loss {final_loss} is not finite after the timed steps: the measurement is INVALID, refusing to print a benchmark line")
+        torch.cuda.synchronize()
+        os._exit(4)
 
     # ---- secondary measurements (single GPU): the same step without clip+AdamW (the metric's "fwd+bwd"), and batch 8 (BASELINE configs[1])
     secondary = {}

@@ -87,8 +87,15 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
         *reinterpret_cast<uint32_t*>(&tile[rh + 16 * i][4 * cq]) = w;   // rows past the end stay zero: they are the K padding of qt
     }
     if constexpr (DELAYED) {
+        // One atomic max per wave on ONE address would be 187 000 serialised atomics for a [46 832, 4096] tensor (~2 ms: round 4 measured the step at
+        // 282 ms that way).  Look first: a wave whose maximum does not beat the running one -- all but a handful, the running maximum of N tiles is
+        // beaten ~ln N times -- leaves it alone.  The look is a relaxed agent-scope load (a stale value only costs a needless atomic, never a lost one).
         amax = wave_max(amax);
-        if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(scales + 3), __float_as_uint(amax));
+        if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) {
+            unsigned* slot = reinterpret_cast<unsigned*>(scales + 3);
+            const unsigned mine = __float_as_uint(amax);
+            if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+        }
     }
     if (!qt) return;
     __syncthreads();
@@ -102,6 +109,69 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
             *reinterpret_cast<uint32_t*>(qt + (long)c * ld_qt + r) = w;
         }
     }
+}
+
+// Row-major copy only (no transposed copy: every activation / gradient of the default fp8 policy): a streaming kernel -- 16-B loads of 8 bf16 (or two
+// of 4 f32), four groups in flight per thread, 8-B stores -- instead of the 64 x 64 transposing tiles above, whose 8-B loads ran at ~3 TB/s.
+template <typename T> TAV_DEV void ld8(const T* p, f32x4& a, f32x4& b);
+template <> TAV_DEV void ld8<float>(const float* p, f32x4& a, f32x4& b) { a = ld4(p); b = ld4(p + 4); }
+template <> TAV_DEV void ld8<bf16>(const bf16* p, f32x4& a, f32x4& b) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+    a = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+    b = f32x4{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u)};
+}
+template <typename T, bool DELAYED>
+__global__ __launch_bounds__(256) void fp8_quantize_stream_kernel(const T* __restrict__ x, float* __restrict__ scales, uint8_t* __restrict__ q, unsigned rows,
+                                                                  unsigned cols8, long ld, long ld_q) {
+    const float sc = scales[0];
+    const unsigned n8 = rows * cols8, stride = gridDim.x * 256u;
+    float amax = 0.f;
+    constexpr int U = 4;
+    for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < n8; i0 += U * stride) {
+        f32x4 a[U], b[U];
+        long qo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            qo[u] = -1;
+            if (i < n8) {
+                const unsigned r = i / cols8, c = (i - r * cols8) * 8u;
+                ld8<T>(x + (long)r * ld + c, a[u], b[u]);
+                qo[u] = (long)r * ld_q + c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (qo[u] < 0) continue;
+            if constexpr (DELAYED) {
+                const f32x4 m = __builtin_elementwise_max(__builtin_elementwise_abs(a[u]), __builtin_elementwise_abs(b[u]));
+                amax = fmaxf(amax, fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
+            }
+            uint2 w;
+            w.x = pack4_fp8(a[u] * sc); w.y = pack4_fp8(b[u] * sc);
+            *reinterpret_cast<uint2*>(q + qo[u]) = w;
+        }
+    }
+    if constexpr (DELAYED) {
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0 && amax > 0.f && amax < 3.0e38f) {      // (as in fp8_quantize_kernel: look before the atomic)
+            unsigned* slot = reinterpret_cast<unsigned*>(scales + 3);
+            const unsigned mine = __float_as_uint(amax);
+            if (mine > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mine);
+        }
+    }
+}
+template <typename T, bool DELAYED>
+static bool quantize_stream(const void* x, int64_t rows, int64_t cols, int64_t ld, float* scales, void* q, int64_t ld_q, hipStream_t st) {
+    // the streaming form needs 16-B aligned groups of 8 and 32-bit group indices
+    if (cols % 8 || ld % 8 || ld_q % 8 || rows * (cols / 8) >= (1ll << 31) || ((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return false;
+    const long n8 = rows * (cols / 8);
+    long nb = (n8 + 256 * 4 - 1) / (256 * 4);
+    nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
+    hipLaunchKernelGGL((fp8_quantize_stream_kernel<T, DELAYED>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, scales, (uint8_t*)q, (unsigned)rows,
+                       (unsigned)(cols / 8), (long)ld, (long)ld_q);
+    return true;
 }
 
 // every state whose running maximum moved this step takes it over as its scale; the others (unused this step, or just calibrated) stay
@@ -151,6 +221,8 @@ extern "C" int tav_fp8_quantize(const void* x, int32_t dtype, int64_t rows, int6
     const long rp = qt ? rows_pad : rows;
     dim3 grid(tav_cdiv(cols, 64), tav_cdiv(rp, 64));
     float* sc = const_cast<float*>(scales);
+    if (!qt && dtype == TAV_BF16 && quantize_stream<bf16, false>(x, rows, cols, ld, sc, q, ld_q, ST)) return tav_last_error();
+    if (!qt && dtype == TAV_F32 && quantize_stream<float, false>(x, rows, cols, ld, sc, q, ld_q, ST)) return tav_last_error();
     if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16, false>), grid, dim3(256), 0, ST, (const bf16*)x, sc, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
     else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float, false>), grid, dim3(256), 0, ST, (const float*)x, sc, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
     else return TAV_ERR_DTYPE;
@@ -163,6 +235,8 @@ extern "C" int tav_fp8_quantize_delayed(const void* x, int32_t dtype, int64_t ro
     if (ld % 4 || (q && ld_q % 4) || (qt && (ld_qt % 4 || rows_pad % 4 || rows_pad < rows || ld_qt < rows_pad))) return TAV_ERR_ALIGN;
     const long rp = qt ? rows_pad : rows;
     dim3 grid(tav_cdiv(cols, 64), tav_cdiv(rp, 64));
+    if (!qt && dtype == TAV_BF16 && quantize_stream<bf16, true>(x, rows, cols, ld, state, q, ld_q, ST)) return tav_last_error();
+    if (!qt && dtype == TAV_F32 && quantize_stream<float, true>(x, rows, cols, ld, state, q, ld_q, ST)) return tav_last_error();
     if (dtype == TAV_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16, true>), grid, dim3(256), 0, ST, (const bf16*)x, state, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
     else if (dtype == TAV_F32) hipLaunchKernelGGL((fp8_quantize_kernel<float, true>), grid, dim3(256), 0, ST, (const float*)x, state, (uint8_t*)q, (uint8_t*)qt, (int)rows, (int)cols, (long)ld, (long)ld_q, (long)ld_qt, (int)rp);
     else return TAV_ERR_DTYPE;

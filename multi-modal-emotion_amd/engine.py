@@ -46,11 +46,13 @@ class Policy:
         self.fp8_wgrad8 = name in ("fp8-wgrad8", "fp8-all")
         # which of a layer's GEMMs take e4m3 operands: bit 0 qkv, 1 out-proj, 2 FFN1, 3 FFN2 -- forward (fwd) and their dgrads (bwd).
         # The others run the bf16 kernels.  (TAV_FP8_FWD_MASK / TAV_FP8_BWD_MASK: error-attribution experiments, tools/gpu_fp8_attrib.py.)
-        # Default (round 3, measured at config 5's REAL depth, 24 video layers, profiles/r03_fp8_attribution.txt): only the QKV projection keeps
-        # e4m3 in the forward pass -- its rounding is averaged by the softmax (logits 6.1e-3 vs bf16's 5.4e-3) -- while e4m3 out-proj /
-        # FFN1 / FFN2 inputs each cost 1.5e-2 .. 2.2e-2 on the logits, over the 1e-2 budget on their own; all four dgrads stay on e4m3
-        # (grad-norm 6.5e-4).  "fp8-all" / "fp8-wgrad8" remain the all-e4m3 throughput experiments.
-        self.fp8_fwd = int(os.environ.get("TAV_FP8_FWD_MASK", "15" if name == "fp8-all" else "1")) if self.fp8 else 0
+        # Default (round 4, measured at config 5's REAL depth -- 24 video layers -- over THREE seeds, profiles/r04_fp8_seeds.txt): NO forward GEMM on
+        # e4m3.  Round 3 kept the QKV projection (logits 6.1e-3 on seed 0), but that was one lucky draw: the same policy gives 1.13e-2 and 1.36e-2 on
+        # seeds 1 and 2 -- over the 1e-2 budget -- with the pre-scaled or the plain q alike (bf16: 5.9e-3 / 7.2e-3 / 4.2e-3); e4m3 out-proj / FFN1 /
+        # FFN2 inputs cost 1.5e-2 .. 2.2e-2 each (profiles/r03_fp8_attribution.txt), also under MX block scales (profiles/r04_fp8_mx_emulation.txt).
+        # All four dgrads stay on e4m3: they cannot touch the logits or the loss, and the gradient norm moves by < 2.5e-3.  TAV_FP8_FWD_MASK=1
+        # restores round 3's policy; "fp8-all" / "fp8-wgrad8" remain the all-e4m3 throughput experiments.
+        self.fp8_fwd = int(os.environ.get("TAV_FP8_FWD_MASK", "15" if name == "fp8-all" else "0")) if self.fp8 else 0
         self.fp8_bwd = int(os.environ.get("TAV_FP8_BWD_MASK", "15")) if self.fp8 else 0
         if self.fp8_wgrad8:
             self.fp8_fwd = self.fp8_bwd = 15             # (the e4m3 weight gradients read the transposed quantised copies of every operand)
@@ -163,7 +165,7 @@ class WeightCache:
         w.r.t. the unscaled q); Wo / W1 / W2 carry both copies.  Weights move little from step to step: delayed scaling (ops.fp8_quantize)."""
         def build():
             wqkv, wqkv_t, _, wo_n, _, w1_n, _, w2_n, _ = self.layer(wq, wk, wv, bq, bk, bv, wo, w1, w2, q_scale=q_scale)
-            f = ops.fp8_quantize(wqkv, want_t=False, state=self.fp8_state(wq, "Wqkv.f"))
+            f = ops.fp8_quantize(wqkv, want_t=False, state=self.fp8_state(wq, "Wqkv.f")) if (self.pol.fp8_fwd & 1) else None
             # the dgrad operand is the transposed copy [K, 3H] of the UNSCALED weight: exactly the row-major e4m3 copy of layer()'s Wqkv^T
             bq8 = ops.fp8_quantize(wqkv_t, want_t=False, state=self.fp8_state(wq, "Wqkv.b"))
             b = ops.Fp8(None, bq8.q, bq8.scales, wqkv_t.shape[1], wqkv_t.shape[0])

@@ -126,6 +126,16 @@ def check_fp8(M=700, N=384, K=1024, tile_m=0):
     rs = [_res("fp8.amax", x8.scales[2:3], amax.reshape(1), 0.0), _res("fp8.scale", x8.scales[0:1], (448.0 / amax).reshape(1), 1e-6)]
     ref_q = (x.float() * x8.scales[0]).to(torch.float8_e4m3fn).float()
     rs.append(_res("fp8.quantize_vs_torch", x8.q.float(), ref_q, 0.0))
+    # the row-major-only form takes the streaming kernel (16-B loads, no transposing tiles): same bytes; and so does its delayed-scaling form
+    x8s = ops.fp8_quantize(x)
+    rs.append(_res("fp8.quantize_stream == tiled", x8s.q.float(), x8.q.float(), 0.0))
+    sts = ops.Fp8States(x.device, n=4)
+    xa = ops.fp8_quantize(x, state=(sts, "x"))             # calibrates
+    xb = ops.fp8_quantize(x, state=(sts, "x"))             # delayed: same scale, gathers the maximum
+    rs.append(_res("fp8.quantize_stream delayed == calibrated", xb.q.float(), xa.q.float(), 0.0))
+    rs.append(_res("fp8.delayed gathered amax", sts.dev[0, 3:4], amax.reshape(1), 0.0))
+    xv = x[:, : K // 2]                                     # a strided view (row stride K, 16-B aligned): still the streaming kernel
+    rs.append(_res("fp8.quantize_stream strided", ops.fp8_quantize(xv).q.float(), (xv.float() * (448.0 / xv.float().abs().max())).to(torch.float8_e4m3fn).float(), 0.0))
     kp = x8.qt.shape[1]
     rs.append(_res("fp8.quantize_t", x8.qt.float()[:, :M], x8.q.float().t(), 0.0))
     rs.append(_res("fp8.quantize_t_pad", x8.qt.float()[:, M:].abs().sum().reshape(1), torch.zeros(1, device=DEV), 0.0))

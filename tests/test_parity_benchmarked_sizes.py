@@ -131,9 +131,9 @@ def test_full_depth_bf16_more_seeds(gpu, seed):
     _compare_with_oracle(_oracle_full("B", seed=seed), "bf16", 1e-2, f"full-depth B seed {seed}")
 
 
-def _c5_oracle():
+def _c5_oracle(seed=0):
     cfg = C.preset("B5")                                       # 12 text / 12 audio / 24 video (1024-16-4096, 32 frames) / 12 fusion layers
-    return _oracle_full("B5", seed=0, batch_size=2, cfg=cfg, tag="B5-full")
+    return _oracle_full("B5", seed=seed, batch_size=2, cfg=cfg, tag="B5-full")
 
 
 @pytest.mark.parametrize("policy,tol,gtol", [("fp32", 1e-3, 1e-3), ("bf16", 1e-2, 5e-2), ("fp8", 1e-2, 0.2)])
@@ -189,3 +189,10 @@ def test_config0_text_classifier_b16_s128_full_depth_bf16(gpu):
     print(f"[configs[0] text classifier b=16 S=128 12 L bf16] logits {e_logits:.2e} loss {e_loss:.2e} grad-norm {e_gn:.2e} worst tensor {worst:.2e} ({worst_k})")
     assert e_logits < 1e-2 and e_loss < 1e-2 and e_gn < 1e-2, (e_logits, e_loss, e_gn)
     assert worst < 5e-2, (worst, worst_k)
+
+
+@pytest.mark.parametrize("policy,tol,gtol", [("bf16", 1e-2, 5e-2), ("fp8", 1e-2, 0.2)])
+def test_config5_full_depth_parity_second_seed(gpu, policy, tol, gtol):
+    """Config 5 at its real depth on ANOTHER seed (weights and inputs).  Round 4 found the round-3 fp8 policy (QKV forward on e4m3) inside the 1e-2 budget
+    on seed 0 only -- 1.13e-2 / 1.36e-2 on seeds 1 / 2 (profiles/r04_fp8_seeds.txt) -- and took every forward GEMM off e4m3; one seed is not a gate."""
+    _compare_with_oracle(_c5_oracle(seed=1), policy, tol, "config 5 full depth, seed 1", grad_tol=gtol)

@@ -1,5 +1,5 @@
 """Config 5 at full depth (24 video layers), batch 2, ONE policy setting from the environment (TAV_FP8_FWD_MASK / TAV_FP8_BWD_MASK / TAV_ATTN_PRESCALE /
-TAV_FP8_DELAYED ...) against the fp32 oracle: logits / loss / grad-norm errors.  usage: python tools/gpu_fp8_one.py [policy] [label]"""
+TAV_FP8_DELAYED ...) against the fp32 oracle: logits / loss / grad-norm errors.  usage: python tools/gpu_fp8_one.py [policy] [label] [seed]"""
 import os
 import sys
 
@@ -16,8 +16,10 @@ from tav_amd.optim import grad_norm  # noqa: E402
 
 pol = sys.argv[1] if len(sys.argv) > 1 else "fp8"
 label = sys.argv[2] if len(sys.argv) > 2 else ""
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 cfg = C.preset("B5")
-cfg, batch, lab, (sdp, sdm), o_logits, o_loss, o_gn, o_grads = T._oracle_full("B5", seed=0, batch_size=2, cfg=cfg, tag="B5-full")
+cfg, batch, lab, (sdp, sdm), o_logits, o_loss, o_gn, o_grads = T._oracle_full("B5", seed=seed, batch_size=2, cfg=cfg, tag="B5-full")
+label = f"{label} seed {seed}"
 runtime.set_precision(pol)
 pre, model = PreFormer(cfg), TAVForMAE(T.ARGS, cfg)
 pre.load_state_dict(sdp)
