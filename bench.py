@@ -318,6 +318,7 @@ def main():
     # hipGraph: capture one whole step (fwd, loss, bwd, clip, AdamW, weight re-casts) and replay it -- ~3000 kernel launches per
     # step would otherwise cost the Python host about as long as the GPU needs to run them.
     graph, eager_step, launch = None, one_step, "eager launches, one stream (--profile-serial)" if args.profile_serial else "eager"
+    abi_comm = None
     if args.graph and stepper.reducer is not None and not args.no_optimizer:
         # Data parallel: the step is a chain of hipGraphs with the gradient all-reduces issued eagerly between them, so that no RCCL
         # call is ever captured (ddp.GraphedStep): the backward is cut into --ddp-segments graphs at bucket boundaries and the
@@ -337,6 +338,7 @@ def main():
         except Exception as e:
             capture_failed(e)
         graph, one_step = gstep, gstep.run
+        abi_comm = gstep.comm                        # (--ddp-mode single: the C ABI's own RCCL communicator, destroyed at exit)
         for _ in range(2):
             one_step()
         torch.cuda.synchronize()
@@ -595,6 +597,9 @@ def main():
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
         print(json.dumps(out), flush=True)
+    if abi_comm is not None:
+        torch.cuda.synchronize()
+        abi_comm.destroy()
     if world > 1 or alone_ddp:
         torch.distributed.destroy_process_group()
 

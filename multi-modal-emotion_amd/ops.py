@@ -425,11 +425,18 @@ def ln_flush():
 
 def _ln_defer_register(part, dgamma, dbeta, nblk, W):
     tid = _graph_task_id()
+    item = (part, dgamma.untyped_storage(), dbeta.untyped_storage(), dgamma.data_ptr(), dbeta.data_ptr(), nblk, W)
     if _ln_pending["task"] != tid:
         # a new backward pass (whatever an aborted earlier one left behind is dropped: its gradients were never consumed)
         _ln_pending["task"], _ln_pending["items"] = tid, []
-        torch.autograd.Variable._execution_engine.queue_callback(ln_flush)
-    _ln_pending["items"].append((part, dgamma.untyped_storage(), dbeta.untyped_storage(), dgamma.data_ptr(), dbeta.data_ptr(), nblk, W))
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(ln_flush)
+        except Exception:                       # (a torch without this private hook: reduce at once and stop deferring)
+            ln_defer[0] = False
+            _ln_pending["items"] = [item]
+            ln_flush()
+            return
+    _ln_pending["items"].append(item)
 
 
 def _grad_free_leaf(p):
