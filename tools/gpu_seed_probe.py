@@ -5,6 +5,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: E402
+
+torch.set_num_threads(16)       # the CPU oracle: the cgroup's threads, not the host's core count
 import test_model_gpu as T  # noqa: E402
 
 preset = sys.argv[1]
