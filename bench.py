@@ -104,6 +104,10 @@ def parse_args():
     ap.add_argument("--reduce-bf16", action="store_true", help="all-reduce gradients in bf16 (halves xGMI bytes)")
     ap.add_argument("--reduce-bf16-tail", action="store_true", help="N > 1: only the LAST bucket (lowest segment: front-ends, embedding tables -- the one "
                     "all-reduce nothing is left to hide behind) crosses xGMI in bf16; every other gradient stays f32 on the wire")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1 (or TAV_DDP_SINGLE_RANK=1), chain mode: bucket ranges are reduced to their OWNER rank only, each rank clips and runs AdamW on the "
+                         "1/N it owns and the updated parameters come back through the buckets (optim.ShardedAdamW; parameters bit-equal to the replicated "
+                         "optimizer's -- tests).  Off by default: it has run with two ranks over gloo only, never on RCCL with N > 1")
     ap.add_argument("--graph", type=int, default=1, help="1: capture the step into hipGraphs and replay them; 0: eager launches (debugging)")
     ap.add_argument("--profile-serial", action="store_true",
                     help="profiling mode: eager launches, every branch on ONE stream, so that a rocprofv3 --kernel-trace --stats of this command sees each "
@@ -117,7 +121,10 @@ def parse_args():
                          "them (rounds 2-3); 'auto' = chain: the single graph is 2 % faster with one rank on RCCL (18.5 vs 19.0 ms at 4 utterances per "
                          "GPU, profiles/r04_ab_ddp.txt) but a captured collective has never met a second rank on this project, and a hang at N = 8 "
                          "would cost the whole scaling measurement -- so the path that has run with two ranks stays the default")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.shard_optimizer and args.ddp_mode == "single":
+        ap.error("--shard-optimizer runs as the graph chain (its exchanges are torch.distributed calls between the graphs): not with --ddp-mode single")
+    return args
 
 
 def self_launch(args):
@@ -334,7 +341,8 @@ def main():
             if args.ddp_mode == "single":
                 gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="single", tail_bf16=args.reduce_bf16_tail)
             if gstep is None:
-                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="chain", tail_bf16=args.reduce_bf16_tail)
+                gstep = GraphedStep(stepper, fwd, work_stream, segments=args.ddp_segments, mode="chain", tail_bf16=args.reduce_bf16_tail,
+                                    shard_optimizer=args.shard_optimizer)
         except Exception as e:
             capture_failed(e)
         graph, one_step = gstep, gstep.run

@@ -381,6 +381,9 @@ int tav_adamw_multi(float* const* params, const float* const* grads, float* cons
 int tav_optim_chunk_elems(void);
 int tav_sumsq_chunked(const float* const* ptrs, const int64_t* sizes, const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks,
                       float* partials, float* out_sumsq, void* stream);
+/* v6: the second stage of tav_sumsq_chunked alone (out = sum of n partials, fixed order): for an optimizer SHARDED over data-parallel ranks, each
+ * of which computes the partials of its own chunks; the exchanged array summed here gives every rank the replicated optimizer's norm, bit for bit. */
+int tav_sum_partials(const float* partials, int64_t n, float* out, void* stream);
 int tav_adamw_chunked(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
                       const int32_t* chunk_prefix, int32_t ntensors, int32_t nchunks, const float* clip_coef, const float* lr, float beta1,
                       float beta2, float eps, float weight_decay, int32_t* step, float* bias_corr, void* stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAV_LIB") or os.path.join(_HERE, "libtavhip.so")      # TAV_LIB: developer knob, A/B of two builds (tools/ab_build.sh)
 
 TAV_F32, TAV_BF16, TAV_FP8 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -143,6 +143,7 @@ _SIGS = {
     "tav_adamw_multi": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
     "tav_optim_chunk_elems": (C.c_int, []),
     "tav_sumsq_chunked": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp]),
+    "tav_sum_partials": (C.c_int, [vp, i64, vp, vp]),
     "tav_adamw_chunked": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp]),
 }
 

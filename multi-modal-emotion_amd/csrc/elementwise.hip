@@ -571,13 +571,20 @@ __global__ __launch_bounds__(256) void adamw_chunk_kernel(float* const* __restri
     float* p = params[t] + off; const float* g = grads[t] + off; float* ea = m1[t] + off; float* es = m2[t] + off;
     long n = sizes[t] - off; n = n < OPT_CHUNK ? n : OPT_CHUNK;
     const float cc = clip_coef ? clip_coef[0] : 1.f;
-    const float decay = 1.f - lr * wd, step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    const float decay = 1.f - lr * wd, step = lr / bc1, rs2 = 1.f / sqrtf(bc2), omb1 = 1.f - b1, omb2 = 1.f - b2;
+    // One arithmetic for every element, whichever of the loops below it falls into: contraction is OFF and the three multiply-adds are written
+    // out, so the 16-byte and the scalar form agree bit for bit.  (With the compiler free to contract, the two forms differed in the last bit of
+    // some weights -- harmless alone, but an optimizer sharded over ranks cuts the tensors elsewhere than the replicated one, lands elements in the
+    // other form, and Adam's m / sqrt(v) turns last-bit differences of near-zero gradients into lr-sized ones within a few steps.)
     auto upd = [&](float& w, float gr, float& a, float& s2) {
-        gr *= cc;
-        w *= decay;
-        a = a * b1 + (1.f - b1) * gr;
-        s2 = s2 * b2 + (1.f - b2) * gr * gr;
-        w -= step * a / (sqrtf(s2) * rs2 + eps);
+#pragma clang fp contract(off)
+        gr = gr * cc;
+        w = w * decay;
+        a = __builtin_fmaf(a, b1, omb1 * gr);
+        s2 = __builtin_fmaf(s2, b2, (omb2 * gr) * gr);
+        const float den = __builtin_fmaf(sqrtf(s2), rs2, eps);
+        const float q = (step * a) / den;
+        w = w - q;
     };
     const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ea) | reinterpret_cast<uintptr_t>(es)) & 15) == 0;
     long done = 0;
@@ -861,6 +868,14 @@ extern "C" int tav_sumsq_chunked(const float* const* ptrs, const int64_t* sizes,
     if (ntensors <= 0 || nchunks <= 0) return TAV_ERR_SHAPE;
     hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(nchunks), dim3(256), 0, ST, ptrs, sizes, chunk_prefix, ntensors, partials);
     hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, ST, partials, (long)nchunks, out_sumsq);
+    return tav_last_error();
+}
+// second stage of tav_sumsq_chunked on its own: a sharded optimizer computes the partials of the chunks it owns, the ranks exchange them, and every
+// rank adds the complete array here -- same kernel, same order, hence the same norm bit for bit as the replicated optimizer's
+extern "C" int tav_sum_partials(const float* partials, int64_t n, float* out, void* stream) {
+    if (!partials || !out) return TAV_ERR_NULL;
+    if (n <= 0) return TAV_ERR_SHAPE;
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, ST, partials, (long)n, out);
     return tav_last_error();
 }
 extern "C" int tav_adamw_chunked(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,

@@ -341,7 +341,7 @@ class GraphedStep:
     `use_graphs=False` runs the same chain eagerly (forward, segments, packs, collectives in the same order) on any device: that is what
     the 2-rank gloo test on the CPU exercises, and a debugging aid on the GPU."""
 
-    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None, mode="chain", tail_bf16=False):
+    def __init__(self, stepper, forward_loss, stream=None, segments=4, use_graphs=True, fractions=None, mode="chain", tail_bf16=False, shard_optimizer=False):
         from . import runtime
         red = stepper.reducer
         self.red, self.stepper, self.stream = red, stepper, stream
@@ -351,6 +351,18 @@ class GraphedStep:
         self.mode = mode if self.use_graphs else "chain"
         self.comm = None
         self.tail_bf16 = bool(tail_bf16)
+        # shard_optimizer: bucket s is reduced to the OWNERS of its ranges instead of all-reduced, each rank clips and updates the ranges it owns
+        # and the updated parameters come back through the buckets (optim.ShardedAdamW: same bytes on the wire, 1/N of the optimizer's work and
+        # state per GPU).  The optimizer then consists of three device phases with two exchanges between them: three graphs in the chain.
+        self.shard = None
+        if shard_optimizer:
+            if self.mode != "chain":
+                raise ValueError("GraphedStep(shard_optimizer=True) runs as the graph chain (mode='chain'): its exchanges are torch.distributed calls")
+            from .optim import ShardedAdamW
+            if not isinstance(stepper.opt, ShardedAdamW):
+                stepper.opt = ShardedAdamW.from_replicated(stepper.opt, red.world, dist.get_rank(red.pg) if dist.is_initialized() else 0, red.pg)
+            self.shard = stepper.opt
+            self.shard.exchange_alone = bool(red._active and red.world == 1)
         self._forward_loss = forward_loss
         k = max(1, int(segments))
         if fractions is None:
@@ -381,11 +393,44 @@ class GraphedStep:
             with runtime.capture(g, stream, pool=g0.pool(), **mode):
                 self._run_and_pack(s)
             self.graphs.append(g)
+        self._adopt_buckets()
+        self.check_plan_across_ranks()
+        if self.shard is not None:
+            self._attach_shards()
+            self.shard.finalize()                                  # (allocates the state slices and tables: outside the captures)
+            self.gu = []
+            for phase in self._shard_phases():
+                g = torch.cuda.CUDAGraph()
+                with runtime.capture(g, stream, pool=g0.pool(), **mode):
+                    phase()
+                self.gu.append(g)
+            return
         self.gu = torch.cuda.CUDAGraph()
         with runtime.capture(self.gu, stream, pool=g0.pool(), **mode):
             stepper.update()
-        self._adopt_buckets()
-        self.check_plan_across_ranks()
+
+    def _attach_shards(self):
+        for s, (plist, flat) in enumerate(self.flats):
+            if plist:
+                self.shard.attach_bucket(s, plist, flat)
+
+    def _shard_phases(self):
+        """The three device phases of the sharded optimizer step (what TrainStep.update() is for the replicated one); exchange_norm() runs
+        between the first two, exchange_params() between the last two."""
+        st, sh = self.stepper, self.shard
+        clip = getattr(st, "clip", None)
+
+        def norm():
+            if clip is not None:
+                sh.phase_norm()
+
+        def update():
+            sh.phase_update(clip)
+
+        def adopt():
+            sh.phase_adopt()
+            sh.zero_grad(set_to_none=getattr(st, "zero_to_none", True))
+        return norm, update, adopt
 
     def _capture_single(self, stepper, forward_loss, stream, mode):
         """Round 4: the WHOLE data-parallel step as ONE hipGraph.  The collective of bucket s is a raw RCCL all-reduce (AbiComm) captured on the
@@ -431,9 +476,22 @@ class GraphedStep:
 
     def _adopt_buckets(self):
         red = self.red
-        red.buckets = [(plist, flat) for plist, flat in self.flats if plist]  # hook mode, if switched back on, reuses these buckets
-        red._bucket_of = {p: i for i, (plist, _) in enumerate(red.buckets) for p in plist}
+        if self.shard is None:
+            red.buckets = [(plist, flat) for plist, flat in self.flats if plist]  # hook mode, if switched back on, reuses these buckets
+            red._bucket_of = {p: i for i, (plist, _) in enumerate(red.buckets) for p in plist}
+        else:
+            red.buckets = None                       # (slice padding sits between gradients and flags: hook mode plans its own buckets)
         red._pending, red._streams, red._works = {}, {}, []
+        self._bucket_norm()
+
+    def _bucket_norm(self):
+        """The replicated optimizer takes the clip norm over the buckets (FusedAdamW.norm_buffers): every gradient of this mode lives in one, four
+        tensors instead of ~400, and the chunk grid a sharded optimizer's ranks reproduce bit for bit."""
+        opt = getattr(self.stepper, "opt", None)
+        if self.shard is None and self.mode == "chain" and opt is not None and hasattr(opt, "prepare_norm_buffers"):
+            opt.norm_buffers = [flat[:sum(p.numel() for p in plist)] for plist, flat in self.flats if plist]
+            if opt.norm_buffers and opt.norm_buffers[0].is_cuda:
+                opt.prepare_norm_buffers()               # (tables uploaded here, between the captures; the single-graph mode keeps the per-parameter norm)
 
     def _bucket_order(self, params):
         """Order of a segment's parameters inside its bucket: as the autograd walk found them, except that the members of one transformer
@@ -462,6 +520,13 @@ class GraphedStep:
                     done.add(id(q))
         return out
 
+    def _flat_elems(self, n, k):
+        """Elements of a bucket buffer for n gradient elements of k parameters: the gradients, the k "used" flags -- and, with a sharded optimizer,
+        room for `world` equal slices in front of the flags, so that reduce-scatter / all-gather can run in place on the buffer's head."""
+        if self.shard is None:
+            return n + k
+        return max(n, self.shard.world * self.shard.slice_elems(n)) + k
+
     def _run_and_pack(self, s):
         from . import runtime
         expected = self._bucket_order([p for p in self.seg.final[s] if p.requires_grad])
@@ -472,10 +537,10 @@ class GraphedStep:
             # allocated inside the capture, i.e. from the graphs' private pool: the reference kept in self.flats pins it for good, and
             # the reducer / RCCL streams only ever touch it between two replays.  (+ the reducer's per-parameter "used" flags, all ones:
             # in this mode every bucketed parameter must produce a gradient every step)
-            if reuse is not None and reuse.numel() == n + len(expected):
+            if reuse is not None and reuse.numel() == self._flat_elems(n, len(expected)):
                 flat = reuse
             else:
-                flat = torch.empty(n + len(expected), dtype=torch.float32, device=expected[0].device)
+                flat = torch.empty(self._flat_elems(n, len(expected)), dtype=torch.float32, device=expected[0].device)
                 flat[n:].fill_(1.0)
             off = 0
             for p in expected:
@@ -500,7 +565,7 @@ class GraphedStep:
             # (no arena, or a parameter of the plan produced no gradient: lay the bucket out from what is there)
             plist = self._bucket_order(plist)
             n = sum(p.numel() for p in plist)
-            flat = torch.empty(n + len(plist), dtype=torch.float32, device=plist[0].device)
+            flat = torch.empty(self._flat_elems(n, len(plist)), dtype=torch.float32, device=plist[0].device)
             flat[n:].fill_(1.0)
             views, off = {}, 0
             for p in plist:
@@ -555,7 +620,14 @@ class GraphedStep:
 
     def _reduce(self, flat, s=None):
         red = self.red
-        if flat is None or not red._active or _SKIP_REDUCE:
+        if flat is None:
+            return
+        if self.shard is not None and s is not None:
+            self.shard.attach_bucket(s, self.flats[s][0], flat)     # (eager chain: the plan is met bucket by bucket in the first pass)
+            if red._active and not _SKIP_REDUCE:
+                self.shard.reduce_to_owners(s, self._wire_dtype(s), average_on_wire=red._avg)
+            return
+        if not red._active or _SKIP_REDUCE:
             return
         wd = self._wire_dtype(s) if s is not None else red.reduce_dtype
         buf = flat if wd is None else flat.to(wd)
@@ -578,6 +650,14 @@ class GraphedStep:
             with torch.cuda.stream(self.side):
                 self._reduce(flat, s)
         _rt().stream_wait(main, self.side)
+        if self.shard is not None:
+            g_norm, g_update, g_adopt = self.gu
+            g_norm.replay()
+            self.shard.exchange_norm()
+            g_update.replay()
+            self.shard.exchange_params()
+            g_adopt.replay()
+            return self.loss
         self.gu.replay()
         return self.loss
 
@@ -611,16 +691,23 @@ class GraphedStep:
             self.check_plan_across_ranks()
         elif sig != self._plan:
             raise RuntimeError(f"data-parallel bucket plan changed between steps: {self._plan} -> {sig}")
+        self._bucket_norm()
         self.stepper.update()
         return self.loss
 
     def describe(self):
         sizes = ", ".join(f"{(flat.numel() * 4 / 2 ** 20) if flat is not None else 0:.0f}" for _, flat in self.flats)
         how = f"{len(self.graphs)} hipGraphs" if self.use_graphs else "eager chain"
-        tot = sum(flat.numel() - len(pl) for pl, flat in self.flats if flat is not None)
+        tot = sum(sum(p.numel() for p in pl) for pl, flat in self.flats if flat is not None)
         arena = f"; gradient arena: {100.0 * getattr(self, 'in_place', 0) / max(tot, 1):.0f} % of the bucket elements written in place by their kernels" if ARENA else ""
         if self.mode == "single":
             return (f"ONE hipGraph (forward, backward in {self.seg.nseg} segments, optimizer); bucket s all-reduced by a CAPTURED raw RCCL call (C ABI "
                     f"tav_allreduce_bucket, RCCL {self.comm.version}) on the reducer branch while segment s+1 runs; buckets [{sizes}] MiB{arena}")
+        if self.shard is not None:
+            own, tot = self.shard.owned_elements() if self.shard._ready else (0, 0)
+            return (f"{how} (forward + backward cut into {self.seg.nseg} segments) + SHARDED optimizer ({'3 graphs' if self.use_graphs else 'calls'}: partial norms | "
+                    f"exchange | clip + AdamW on the owned ranges | parameter broadcast | adopt); bucket s reduced to its range owners "
+                    f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; this rank owns {100.0 * own / max(tot, 1):.1f} % of "
+                    f"{tot} elements; buckets [{sizes}] MiB{arena}")
         return (f"{how} (forward + backward cut into {self.seg.nseg} segments) + optimizer {'graph' if self.use_graphs else 'call'}; bucket s all-reduced "
                 f"({'RCCL' if self.red._avg else 'gloo'}, eager, side stream) while segment s+1 runs; buckets [{sizes}] MiB{arena}")

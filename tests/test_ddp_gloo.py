@@ -304,3 +304,149 @@ def test_segmented_backward_bucket_chain_two_ranks(segments):
     assert nseg == (segments if segments != 8 else nseg) and nseg >= 1
     assert sum(n for n, _ in all_sigs[0][0]) == 1 + 2 * (12 + 6 + 2) + 2     # every parameter in exactly one bucket
     assert updates == 3 and "eager chain" in desc
+
+
+# ---- optimizer sharded over the ranks (optim.ShardedAdamW driven by ddp.GraphedStep(shard_optimizer=True)) ----------------------------
+# The clip + AdamW arithmetic of the product is HIP only; what runs here, without a GPU, is everything around it: the owner ranges
+# (shard_cuts), the reduce-to-owner and broadcast exchanges, the scatter of the norm partials, the piece bookkeeping, the state hand-over
+# from a replicated optimizer and the checkpoint gather.  The arithmetic is substituted by this file's torch stand-in -- the SAME stand-in
+# for the sharded optimizer and for the replicated reference it must reproduce bit for bit (chunked partial sums in the replicated order).
+def _cpu_sharded_class():
+    from tav_amd.optim import ShardedAdamW
+
+    class CpuSharded(ShardedAdamW):
+        CHUNK = 4
+
+        def chunk_elems(self):
+            return self.CHUNK
+
+        def _build_tables(self, dev, ce):
+            super()._build_tables(dev, ce)
+            self._norm_local = None
+
+        def _math_partials(self):
+            return torch.stack([t[a:a + self.CHUNK].square().sum() for t in self._slices for a in range(0, t.numel(), self.CHUNK)])
+
+        def _math_coef(self, max_norm):
+            norm = self._part_all[:self._nchunks_all].sum().sqrt()
+            self._scal[2] = norm
+            self._scal[1] = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+
+        def _math_update(self, clipped):
+            self._step_dev += 1
+            t = int(self._step_dev.item())
+            b1, b2 = self.betas
+            coef = self._scal[1] if clipped else 1.0
+            for (p, off, n, flat, pos, a) in self._mine:
+                w, g = p.detach().view(-1)[off:off + n], flat[pos:pos + n] * coef
+                m, v = self._m[a:a + n], self._v[a:a + n]
+                w.mul_(1 - self.lr * self.weight_decay)
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                w.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + self.eps, value=-self.lr)
+
+    return CpuSharded
+
+
+def _worker_sharded_optimizer(rank, world, port, out):
+    import copy
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tav_amd.ddp import BucketedAllReduce, GraphedStep
+    Cpu = _cpu_sharded_class()
+    torch.manual_seed(0)
+    xs = torch.randn(4, 8, 8, generator=torch.Generator().manual_seed(5))
+
+    def build():
+        bs = torch.nn.ModuleList([_Branch("a", 12), _Branch("b", 6), _Branch("c", 2)])
+        emb = torch.nn.Parameter(torch.randn(8))
+        head = torch.nn.Linear(24, 3)
+        return bs, emb, head
+
+    def make(mods, sharded):
+        bs, emb, head = mods
+        params = [emb] + list(bs.parameters()) + list(head.parameters())
+        state = dict(step=0)
+        rows = slice(4 * rank, 4 * rank + 4)
+
+        class Stepper:
+            reducer = BucketedAllReduce(params, bucket_mb=48.0)
+            clip, zero_to_none = 0.05, True                      # (gradient norms here are ~0.3: the clip is active)
+            opt = Cpu(params, world if sharded else 1, rank if sharded else 0, lr=1e-2, weight_decay=1e-2)
+            norms = []
+
+            def update(self):
+                if not sharded and not self.opt.buckets:          # the replicated reference: one "rank" that owns every range
+                    for s, (plist, flat) in enumerate(gs.flats):
+                        if plist:
+                            self.opt.attach_bucket(s, plist, flat)
+                self.norms.append(self.opt.clip_and_step(self.clip).clone())
+                self.opt.zero_grad(set_to_none=True)
+
+        st = Stepper()
+        gs = GraphedStep(st, lambda: head(torch.cat([b(xs[state["step"]][rows] + emb) for b in bs], 1)).square().mean(), stream=None, segments=4,
+                         use_graphs=False, shard_optimizer=sharded)
+        return params, state, st, gs
+
+    ref_mods = build()
+    sh_mods = copy.deepcopy(ref_mods)
+    rp, rstate, rst, rgs = make(ref_mods, False)
+    sp, sstate, sst, sgs = make(sh_mods, True)
+    for step in range(3):
+        rstate["step"] = sstate["step"] = step
+        rgs.run()
+        sgs.run()
+    same = all(torch.equal(a, b) for a, b in zip(rp, sp))
+    norms_same = all(torch.equal(a, b) for a, b in zip(rst.norms, sst.norms))
+    own, tot = sst.opt.owned_elements()
+    # checkpoint: the gathered state equals the replicated optimizer's, and a fresh sharded optimizer loaded from it continues identically
+    sd_ref, sd_sh = rst.opt.state_dict(), sst.opt.state_dict()
+    sd_same = all(torch.equal(sd_ref["state"][i][k], sd_sh["state"][i][k]) for i in sd_ref["state"] for k in ("exp_avg", "exp_avg_sq")) \
+        and sorted(sd_ref["state"]) == sorted(sd_sh["state"]) and all(float(sd_sh["state"][i]["step"]) == 3.0 for i in sd_sh["state"])
+    sst.opt.load_state_dict(sd_ref)                                # (already sharded: every rank takes its slices)
+    rstate["step"] = sstate["step"] = 3
+    rgs.run()
+    sgs.run()
+    resumed_same = all(torch.equal(a, b) for a, b in zip(rp, sp))
+    cuts = {b: c for b, (_, _, c) in sst.opt.buckets.items()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (same, norms_same, sd_same, resumed_same, own, tot, cuts, [n.item() for n in sst.norms], sgs.describe()))
+    if rank == 0:
+        out.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_two_ranks_bit_equal_to_replicated():
+    """reduce to owners, clip + AdamW on 1/N, parameters back through the buckets -- against the replicated optimizer behind the
+    all-reduce chain: parameters, gradient norms and the gathered optimizer state bit-equal on both ranks over three steps, and over a fourth
+    after a load_state_dict into the sharded optimizer."""
+    got = _spawn(_worker_sharded_optimizer)
+    for same, norms_same, sd_same, resumed_same, own, tot, cuts, norms, desc in got:
+        assert same and norms_same and sd_same and resumed_same, (same, norms_same, sd_same, resumed_same)
+        assert all(n > 0.05 for n in norms), norms                 # the clip was active: the exchanged norm mattered
+        assert "SHARDED optimizer" in desc
+    (own0, tot0), (own1, tot1) = (got[0][4], got[0][5]), (got[1][4], got[1][5])
+    assert tot0 == tot1 and own0 + own1 == tot0 and 0.3 < own0 / tot0 < 0.7      # disjoint, complete, roughly balanced
+    assert got[0][6] == got[1][6]                                   # both ranks cut the buckets at the same places
+
+
+def test_shard_cuts_are_equal_whole_chunk_slices():
+    from tav_amd.optim import shard_cuts, shard_pieces, shard_slice
+    for n in (1, 100, 16384, 16385, 458_000_000, 3 * 16384):
+        for world in (1, 2, 3, 8):
+            cuts, L = shard_cuts(n, world, 16384), shard_slice(n, world, 16384)
+            assert cuts[0] == 0 and cuts[-1] == n and cuts == sorted(cuts) and len(cuts) == world + 1
+            assert L % 16384 == 0 and world * L >= n and (world * (L - 16384) < n or L == 16384)     # the smallest whole-chunk slice that covers n
+            assert all(c == min(r * L, n) for r, c in enumerate(cuts[:-1]))
+
+    class P:
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+    sizes = [10, 40000, 5, 16384 * 3 + 7, 768, 2359296]
+    plist = [P(n) for n in sizes]
+    cuts = shard_cuts(sum(sizes), 3, 16384)
+    seen = sorted((pos, pos + n) for r in range(3) for (_, _, n, pos) in shard_pieces(plist, cuts, r))
+    assert seen[0][0] == 0 and seen[-1][1] == sum(sizes) and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))

@@ -979,3 +979,106 @@ def test_c_abi_allreduce_bucket_single_rank(gpu):
         assert h.tav_allreduce_bucket(None, 4, 0, comm, stream()) == -1 and h.tav_allreduce_bucket(ptr(x), 3, 0, comm, stream()) == -2
     finally:
         assert h.tav_comm_destroy(comm) == 0
+
+
+# ---- optimizer sharded over data-parallel ranks: the HIP kernels, two ranks on ONE GPU over gloo ----------------------
+def _worker_sharded_step(rank, world, port, use_graphs, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tav_amd import engine
+        from tav_amd.ddp import GraphedStep
+        from tav_amd.optim import ShardedAdamW
+        from tav_amd.train_model.tav_train import TrainStep
+        from tav_amd.utils.global_functions import CrossEntropyLoss
+        torch.cuda.set_device(0)
+        cfg = C.preset("B")
+        for k in ("text", "audio", "video", "fusion"):
+            cfg[k]["layers"] = 4
+        cfg["video"]["image"] = 32
+        runtime.set_precision("bf16")
+
+        def build():
+            torch.manual_seed(0)
+            pre, model = PreFormer(cfg), TAVForMAE(ARGS, cfg)
+            synthetic.seeded_init_(pre, 1)
+            synthetic.seeded_init_(model, 2)
+            pre.cuda()
+            model.cuda()
+            return TrainStep(model, pre, CrossEntropyLoss(), lr=1e-3, weight_decay=1e-2, clip=1.0)
+
+        s = torch.cuda.Stream()
+        res = {}
+        with torch.cuda.stream(s):
+            inp, lab = synthetic.make_batch(cfg, 2, seed=100 + rank, s_text=16, t_audio=8000, n_visual_true=4, device="cuda")   # this rank's utterances
+            for name, sharded in (("replicated", False), ("sharded", True)):
+                st = build()
+                assert st.reducer is not None
+                st.forward_backward(inp, lab, check="val", epoch=0, n_visual_true=4)       # bench.py's eager warm-up step: hook-mode all-reduce,
+                st.update()                                                                # replicated AdamW -> the moments the shards inherit
+                torch.cuda.synchronize()
+                st.opt.zero_grad()
+                g = GraphedStep(st, lambda: st.forward_loss(inp, lab, check="val", epoch=0, n_visual_true=4), s, segments=4, mode="chain",
+                                use_graphs=use_graphs, shard_optimizer=sharded)
+                losses, norms = [], []
+                for _ in range(2):
+                    losses.append(g.run().item())
+                    norms.append(st.opt.last_norm.item())
+                torch.cuda.synchronize()
+                norm = norms
+                extra = {}
+                if sharded:
+                    assert isinstance(st.opt, ShardedAdamW) and len(st.opt.state) == 0
+                    own, tot = st.opt.owned_elements()
+                    extra = dict(own=own, tot=tot, desc=g.describe(), state_elems=st.opt._m.numel(), sd=st.opt.state_dict())
+                else:
+                    extra = dict(sd=st.opt.state_dict())
+                res[name] = dict(params=[p.detach().clone() for p in st.params], losses=losses, norm=norm, steps=st.opt.step_count, **extra)
+                st.reducer.remove()
+                engine.bump_weight_epoch()
+        a, b = res["replicated"], res["sharded"]
+        same = all(torch.equal(x, y) for x, y in zip(a["params"], b["params"]))
+        worst = max((x - y).abs().max().item() for x, y in zip(a["params"], b["params"]))
+        sd_same = sorted(a["sd"]["state"]) == sorted(b["sd"]["state"]) and all(
+            torch.equal(a["sd"]["state"][i][k], b["sd"]["state"][i][k]) for i in a["sd"]["state"] for k in ("exp_avg", "exp_avg_sq"))
+        moved = max((x - y).abs().max().item() for x, y in zip(a["params"], build().params))
+        got = [None] * world
+        dist.all_gather_object(got, dict(same=same, worst=worst, sd_same=sd_same, moved=moved, losses=(a["losses"], b["losses"]), norms=(a["norm"], b["norm"]),
+                                         steps=(a["steps"], b["steps"]), own=b["own"], tot=b["tot"], state_elems=b["state_elems"], desc=b["desc"]))
+        if rank == 0:
+            out.put(got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graphs", [True])      # (False -- the eager chain -- passes too, 4 min; its host logic is what tests/test_ddp_gloo.py runs on the CPU)
+def test_sharded_optimizer_two_ranks_one_gpu(gpu, use_graphs):
+    """optim.ShardedAdamW with the HIP kernels behind ddp.GraphedStep(shard_optimizer=True): two ranks (two processes on this GPU, gloo), each with its own
+    utterances, one eager warm-up step with the replicated optimizer, then two steps of the chain.  Against the same chain with the all-reduce and the
+    replicated FusedAdamW: parameters, losses, the clipped gradient norm and the gathered optimizer state are bit-equal on both ranks; each rank holds
+    about half of the moments.  use_graphs=True is bench.py's form (segment graphs + three optimizer graphs, the exchanges between them)."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded_step, args=(r, 2, port, use_graphs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        assert p.exitcode == 0
+    got = q.get(timeout=10)
+    print("sharded optimizer:", got[0]["desc"], "| worst", [g["worst"] for g in got], "| norms", got[0]["norms"], "| moved", got[0]["moved"])
+    for g in got:
+        assert g["same"] and g["sd_same"], g["worst"]
+        assert g["losses"][0] == g["losses"][1] and g["norms"][0] == g["norms"][1] and g["steps"][0] == g["steps"][1]
+        assert g["moved"] > 1e-4                                  # the steps did change the parameters
+        assert 0.4 < g["own"] / g["tot"] < 0.6 and g["own"] <= g["state_elems"] < g["own"] + 64 * 600      # (each piece's moments padded to 256 bytes)
+    assert got[0]["own"] + got[1]["own"] == got[0]["tot"]
+    assert got[0]["losses"] != got[1]["losses"]                   # two different batches went in
