@@ -229,6 +229,57 @@ def test_fused_adamw_matches_torch(gpu):
             assert rel(p, q) < 1e-5
 
 
+def test_fused_adamw_bucket_norm_and_misaligned_pieces(gpu):
+    """Round 4, the two properties the sharded optimizer rests on.  (a) FusedAdamW.norm_buffers: the clip norm taken over flat gradient buckets
+    (chunks counted from each bucket's start) is the per-parameter norm up to summation order, and tav_sum_partials over the exchanged partial
+    array reproduces tav_sumsq_chunked's own second stage bit for bit.  (b) adamw_chunk_kernel computes the same bits whether an element falls
+    into its 16-byte or its scalar loop: a tensor updated whole equals the same tensor updated as two pieces cut at an odd element."""
+    import ctypes as Ct
+    from tav_amd._lib import check, lib, ptr, stream
+    from tav_amd.optim import bucket_norm_tables
+    torch.manual_seed(1)
+    shapes = [(768, 768), (3072,), (7, 3072), (5,), (50, 3, 10), (40000,)]
+    n_all = sum(int(np.prod(s)) for s in shapes)
+    flat = torch.randn(n_all + len(shapes), device="cuda")
+    ps, off = [], 0
+    for s_ in shapes:
+        p = torch.nn.Parameter(torch.randn(s_, device="cuda"))
+        k = p.numel()
+        p.grad = flat[off:off + k].view_as(p)
+        off += k
+        ps.append(p)
+    a, b = FusedAdamW(ps, lr=1e-3), FusedAdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    for q, p in zip(b.params, ps):
+        q.grad = p.grad
+    b.norm_buffers = [flat[:n_all]]
+    na, nb = a.clip_and_step(1.0).item(), b.clip_and_step(1.0).item()
+    assert abs(na - nb) / na < 1e-6 and abs(na - flat[:n_all].double().norm().item()) / na < 1e-6
+    for p, q in zip(ps, b.params):
+        assert rel(p, q) < 1e-6
+    # second stage alone == second stage inside tav_sumsq_chunked
+    _, t_g, t_s, t_c, nbuf, nch, part = bucket_norm_tables([flat[:n_all]], int(lib().tav_optim_chunk_elems()))
+    out1, out2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    check(lib().tav_sumsq_chunked(ptr(t_g), ptr(t_s), ptr(t_c), nbuf, nch, ptr(part), ptr(out1), stream()), "sumsq_chunked")
+    check(lib().tav_sum_partials(ptr(part), nch, ptr(out2), stream()), "sum_partials")
+    assert torch.equal(out1, out2) and nch == (n_all + 16383) // 16384
+    # (b) whole tensor vs two pieces cut at element 16384 + 1 (the second piece starts 4 bytes off a 16-byte boundary)
+    n, cut = 3 * 16384 + 11, 16384 + 1
+    w0, g0 = torch.randn(n, device="cuda"), torch.randn(n, device="cuda") * 1e-3
+    whole = FusedAdamW([torch.nn.Parameter(w0.clone())], lr=1e-3, weight_decay=1e-2)
+    whole.params[0].grad = g0.clone()
+    wp = torch.nn.Parameter(w0.clone())
+    pieces = [torch.nn.Parameter(wp.detach()[:cut]), torch.nn.Parameter(wp.detach()[cut:])]
+    split = FusedAdamW(pieces, lr=1e-3, weight_decay=1e-2)
+    for _ in range(3):
+        whole.params[0].grad = g0.clone()
+        pieces[0].grad, pieces[1].grad = g0[:cut].clone(), g0.clone()[cut:]       # (the second gradient view is misaligned too)
+        whole.clip_and_step(None)
+        split.clip_and_step(None)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.params[0].detach(), wp.detach())
+    assert torch.equal(whole.state[whole.params[0]][0][cut:], split.state[pieces[1]][0])
+
+
 def test_grad_accum_second_step_under_both_zero_grad_readings(gpu):
     """reference train_model/tav_train.py:96-106: step, zero_grad, then -- at a dialogue end -- a second unclipped optimizer.step().  Under torch 1.10
     (the reference's pin) zero_grad zero-fills and that step decays the weights and moves them along the momentum; under torch >= 2 it is a no-op.
