@@ -528,6 +528,13 @@ template <> TAV_DEV uint4 tn_frag<float>(const char* tile, int krow0, int col0, 
 // K-tile and ring depth per dtype (64 tokens, two buffers).  A deeper ring of shorter tiles at the same LDS budget (32 tokens x 4 buffers,
 // three tiles in flight) was tried on the theory that a workgroup's K-tile period is one DMA round trip: it is not -- that variant pays
 // twice the barriers and ran 17 % slower (profiles/r02_experiments.md).
+// Bias gradients (column sums of dY) on the matrix pipe: one extra MFMA per 16-column dY fragment with an all-ones first operand gives the
+// column sums of that fragment's K-step in every accumulator row -- the dY fragments are in registers anyway, so the sums cost no LDS reads
+// (rounds 1-3 read 32 two-byte LDS values per thread and K-tile: 16-33 us of every layer's launch).  f32 accumulation of exact products.
+template <typename T> TAV_DEV uint4 ones_frag();
+template <> TAV_DEV uint4 ones_frag<bf16>() { return make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); }
+template <> TAV_DEV uint4 ones_frag<float>() { return make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u); }
+
 template <typename T> struct TNShape { static constexpr int KT = 64, NST = 2; };
 template <> struct TNShape<bf16> {
 #ifdef TAV_ABL_TN_RING4
@@ -585,7 +592,9 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     // launch) 7-30 % longer; spread over the tile row every tile pays 1/tiles_2 of it.
     const bool do_bias = p.bias_part != nullptr && (p.bias_spread || t2 == 0);
     const int bias_mod = p.bias_spread ? p.tiles_2 : 1, bias_rem = p.bias_spread ? t2 : 0;
-    float bsum = 0.f;
+    // the two waves that share a dY block (w2 = 0 / 1) take two of its four 16-column fragments each
+    f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const uint4 ones = ones_frag<T>();
 
     const int nrows = row_end - row_begin;
     const int nk = (nrows + KT - 1) / KT;
@@ -635,6 +644,7 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     auto compute = [&](int cur, int kt_now) {
         const char* cA = sA + cur * TILE_BYTES;
         const char* cB = sB + cur * TILE_BYTES;
+        const bool bias_now = do_bias && (kt_now % bias_mod) == bias_rem;
 #pragma unroll
         for (int s = 0; s < KT / KSTEP; ++s) {
             uint4 f1[4], f2[4];
@@ -647,13 +657,9 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) mma16<T>(f2[b], f1[a], acc[a][b]);   // rows(regs) = n2, cols(lanes) = n1
-        }
-        if (do_bias && (kt_now % bias_mod) == bias_rem) {      // column (tid & 127) of the dY tile, token rows (tid >> 7) * KT/2 .. + KT/2 - 1
-            const int col = tid & 127, cbyte = col * ES;
-#pragma unroll 8
-            for (int r = 0; r < KT / 2; ++r) {
-                const int row = (tid >> 7) * (KT / 2) + r;
-                bsum += ET<T>::ld(reinterpret_cast<const T*>(cA + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
+            if (bias_now) {                                      // (block-uniform; w2 wave-uniform)
+                if (w2 == 0) { mma16<T>(ones, f1[0], bacc[0]); mma16<T>(ones, f1[1], bacc[1]); }
+                else { mma16<T>(ones, f1[2], bacc[0]); mma16<T>(ones, f1[3], bacc[1]); }
             }
         }
     };
@@ -681,12 +687,13 @@ TAV_DEV void gemm_tn_body(const GemmTN& p, const int tile, const int split) {
     }
     __syncthreads();
 
-    if (do_bias) {
-        float* red = reinterpret_cast<float*>(smem);
-        red[tid] = bsum;
-        __syncthreads();
+    if (do_bias && g == 0) {                                 // every accumulator row holds the sums: lanes 0-15 (row 0) write them
         const long slot = p.bias_spread ? (long)split * p.tiles_2 + t2 : split;
-        if (tid < 128 && n1_0 + tid < p.N1) p.bias_part[slot * p.N1 + n1_0 + tid] = red[tid] + red[128 + tid];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n1 = n1_0 + w1 * 64 + (2 * w2 + j) * 16 + i;
+            if (n1 < p.N1) p.bias_part[slot * p.N1 + n1] = bacc[j][0];
+        }
     }
     float* S = p.S + (long)split * p.N1 * p.N2;
 #pragma unroll
@@ -818,7 +825,8 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.bias_part != nullptr && (p.bias_spread || t2 == 0);
     const int bias_mod = p.bias_spread ? p.tiles_2 : 1, bias_rem = p.bias_spread ? t2 : 0;
-    float bsum = 0.f;
+    f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // (see ones_frag: w2 = 0 / 1 take two dY fragments each)
+    const uint4 ones = ones_frag<T>();
 
     // The DMA pieces of later K-tiles (8 per wave and iteration) are issued between the MFMA groups of the first K-step: back to back right
     // after the barrier they cost every wave of the CU ~1000 cycles of issue time at the same moment, with nothing on the matrix pipe.
@@ -839,6 +847,7 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
         const unsigned ka = (unsigned)(kt + AHEAD_A) * strideA, kb = (unsigned)(kt + 1) * strideB;
         const char* cA = smem + ca * IMG + (w1 >> 1) * SUB;
         const char* cB = smem + OFF_B + cb * IMG + w2 * SUB;
+        const bool bias_now = do_bias && (kt % bias_mod) == bias_rem;
 #pragma unroll
         for (int s2 = 0; s2 < KT / KSTEP; ++s2) {
             uint4 f1[4], f2[8];
@@ -858,26 +867,22 @@ TAV_DEV void gemm_tn_big_body(const GemmTN& p, const int tile, const int split) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
-        if (do_bias && (kt % bias_mod) == bias_rem) {      // column (tid & 255) of the dY tile, token rows (tid >> 8) * 32 .. + 31
-            const int col = tid & 255, cbyte = (col & 127) * ES;
-            const char* img = smem + ca * IMG + (col >> 7) * SUB;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const int row = (tid >> 8) * 32 + r;
-                bsum += ET<T>::ld(reinterpret_cast<const T*>(img + row * ROWB + (TT::sw(row, cbyte >> 4) << 4) + (cbyte & 15)));
+            if (bias_now) {
+                if (w2 == 0) { mma16<T>(ones, f1[0], bacc[0]); mma16<T>(ones, f1[1], bacc[1]); }
+                else { mma16<T>(ones, f1[2], bacc[0]); mma16<T>(ones, f1[3], bacc[1]); }
             }
         }
         ca = R25 ? (ca == 2 ? 0 : ca + 1) : (ca ^ 1);
     }
     __syncthreads();
 
-    if (do_bias) {
-        float* red = reinterpret_cast<float*>(smem);
-        red[tid] = bsum;
-        __syncthreads();
+    if (do_bias && g == 0) {
         const long slot = p.bias_spread ? (long)split * p.tiles_2 + t2 : split;
-        if (tid < 256 && n1_0 + tid < p.N1) p.bias_part[slot * p.N1 + n1_0 + tid] = red[tid] + red[256 + tid];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n1 = n1_0 + w1 * 64 + (2 * w2 + j) * 16 + i;
+            if (n1 < p.N1) p.bias_part[slot * p.N1 + n1] = bacc[j][0];
+        }
     }
     float* S = p.S + (long)split * p.N1 * p.N2;
 #pragma unroll

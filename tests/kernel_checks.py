@@ -647,8 +647,8 @@ def all_checks():
             out.append(lambda d=dtype: check_gemm_nt(d, M=700, N=768, K=64, tile_m=16, out_f32=True))
             out.append(lambda d=dtype: check_gemm_nt(d, M=1000, N=3072, K=768, act=1, pre=True, resid=False, tile_m=16))
             out.append(lambda d=dtype: check_gemm_nt(d, M=513, N=132, K=1536, tile_m=16))
-            # interior tiles of the four layer flavours leave straight from the accumulator registers (no bias / bias, bf16 / f32 out, with and
-            # without the f32 residual); the gelu pair below covers the other two flavours, the mixed-schedule check their bit-equality with the staged form
+            # interior tiles (the bounds-check-free pass) of the plain and residual flavours: no bias / bias, bf16 / f32 out, with and without the
+            # f32 residual; the gelu pair below covers the other two flavours
             for kw in (dict(resid=False), dict(resid=False, bias=False), dict(resid=False, out_f32=True), dict(resid=False, bias=False, out_f32=True),
                        dict(out_f32=True), dict(bias=False, out_f32=True)):
                 out.append(lambda d=dtype, k=kw: check_gemm_nt(d, M=700, N=768, K=192, tile_m=16, **k))
