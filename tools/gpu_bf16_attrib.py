@@ -11,10 +11,13 @@ seed = sys.argv[2] if len(sys.argv) > 2 else "0"
 if os.environ.get("TAV_ATTRIB_CHILD") != "1":
     for br in ("", "fusion", "video", "audio", "text", "fusion,video,audio,text"):
         env = dict(os.environ, TAV_F32_BRANCHES=br, TAV_ATTRIB_CHILD="1")
+        print(f"[bf16 attribution] case: fp32 stacks = {br or '(none)'}", flush=True)      # (a line a minute: silent runs are taken to be hung)
         subprocess.run([sys.executable, os.path.abspath(__file__), preset, seed], env=env, check=False)
     sys.exit(0)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch  # noqa: E402
+
+torch.set_num_threads(int(os.environ.get("TAV_CPU_THREADS", "16")))      # the CPU oracle: a one-GPU box gives 16 threads, torch would take the host's count
 
 import test_model_gpu as T  # noqa: E402
 from tav_amd import runtime  # noqa: E402
