@@ -106,6 +106,18 @@ class FusedAdamW:
                     raise RuntimeError("FusedAdamW: run one eager optimizer step before capturing the step into a hipGraph")
                 self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
 
+    def _grads_in_norm_buffers(self, act):
+        """norm_buffers is a promise about where the gradients live; a step whose gradients are somewhere else (a plain eager backward after the
+        graph chain set the buffers) must not take its norm from stale buckets: every active gradient has to lie inside one of the buffers and the
+        buffers must hold nothing else -- otherwise the per-parameter norm is used.  Checked once per set of gradient addresses."""
+        key = tuple(p.grad.data_ptr() for p in act)
+        if getattr(self, "_norm_ok_key", None) != key:
+            spans = [(b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()) for b in self.norm_buffers]
+            inside = all(any(lo <= p.grad.data_ptr() and p.grad.data_ptr() + p.grad.numel() * p.grad.element_size() <= hi for lo, hi in spans) for p in act)
+            self._norm_ok = inside and sum(p.grad.numel() for p in act) == sum(b.numel() for b in self.norm_buffers)
+            self._norm_ok_key = key
+        return self._norm_ok
+
     def prepare_norm_buffers(self):
         """Device tables of norm_buffers (built on first use or when the buffers changed; allocates and uploads: not inside a capture)."""
         if self._norm_tables is None or self._norm_tables[0] != [(b.data_ptr(), b.numel()) for b in self.norm_buffers]:
@@ -139,7 +151,7 @@ class FusedAdamW:
             self._chunks = (sizes, prefix.to(act[0].device), int(counts.sum()))
         d_c, nchunks = self._chunks[1], self._chunks[2]
         coef = None
-        if max_norm is not None and self.norm_buffers:
+        if max_norm is not None and self.norm_buffers and self._grads_in_norm_buffers(act):
             _, t_g, t_s, t_c, nb, nch, part = self.prepare_norm_buffers()
             check(lib().tav_sumsq_chunked(ptr(t_g), ptr(t_s), ptr(t_c), nb, nch, ptr(part), ptr(self._scal[0:1]), stream()), "sumsq_chunked")
         elif max_norm is not None:

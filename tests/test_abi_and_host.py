@@ -634,3 +634,21 @@ def test_head_mask_layouts_and_oracle_head_mask():
     assert y.shape == x.shape and probs[0].shape == (2, 12, 5, 5)
     assert torch.allclose(probs[0][:, 3], m.expand(2, 1, 5, 5)[:, 0])
     assert torch.allclose(probs[0][:, 0].sum(-1), torch.full((2, 5), 1.0 - 0.5), atol=1e-5)
+
+
+def test_bucket_norm_is_used_only_when_the_gradients_live_in_the_buckets():
+    """FusedAdamW.norm_buffers (set by the data-parallel graph chain) must not be trusted by a later step whose gradients are elsewhere."""
+    import torch
+    from tav_amd.optim import FusedAdamW
+    flat = torch.zeros(10 + 6 + 3)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 6)]
+    opt = FusedAdamW(ps)
+    opt.norm_buffers = [flat[:16]]
+    ps[0].grad, ps[1].grad = flat[:10], flat[10:16]
+    assert opt._grads_in_norm_buffers(ps)                       # both gradients are views of the bucket, which holds nothing else
+    ps[1].grad = torch.zeros(6)                                 # a plain backward re-allocated one of them
+    assert not opt._grads_in_norm_buffers(ps)
+    ps[1].grad = flat[10:16]
+    opt.norm_buffers = [flat[:19]]                              # the bucket holds 3 elements that are nobody's gradient
+    opt._norm_ok_key = None
+    assert not opt._grads_in_norm_buffers(ps)
