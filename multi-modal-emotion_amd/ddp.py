@@ -399,7 +399,10 @@ class GraphedStep:
             self._attach_shards()
             self.shard.finalize()                                  # (allocates the state slices and tables: outside the captures)
             self.gu = []
-            for phase in self._shard_phases():
+            for k, phase in enumerate(self._shard_phases()):
+                if k == 0 and getattr(stepper, "clip", None) is None:
+                    self.gu.append(None)                   # no clipping: no norm phase, no exchange of partials (an empty capture is not a graph)
+                    continue
                 g = torch.cuda.CUDAGraph()
                 with runtime.capture(g, stream, pool=g0.pool(), **mode):
                     phase()
@@ -652,8 +655,9 @@ class GraphedStep:
         _rt().stream_wait(main, self.side)
         if self.shard is not None:
             g_norm, g_update, g_adopt = self.gu
-            g_norm.replay()
-            self.shard.exchange_norm()
+            if g_norm is not None:
+                g_norm.replay()
+                self.shard.exchange_norm()
             g_update.replay()
             self.shard.exchange_params()
             g_adopt.replay()
