@@ -59,7 +59,7 @@ if "gemm" in what:
         lo, med = timeit(lambda: ops.gemm_nt(a, b, bias=bias))
         print(f"[{tag}] gemm_nt {name:12s} M={M:6d} N={N:5d} K={K:5d}: min {lo:8.1f} us  med {med:8.1f} us  {2 * M * N * K / lo / 1e6:7.1f} TF")
 if "layer" in what:       # the eight NT GEMMs of ONE video-encoder layer (forward + dgrad) with their real epilogues, and their sum
-    M, H, F = B * 1464, 768, 3072
+    M, H, F = B * int(os.environ.get("TAV_S", "1464")), 768, 3072     # TAV_S: tokens per utterance (1464 video, 481 fusion, 249 audio, 128 text)
     x_lp, w_qkv, w_o, w_1, w_2 = rnd(M, H), rnd(3 * H, H), rnd(H, H), rnd(F, H), rnd(H, F)
     w_qkv_t, w_o_t, w_1_t, w_2_t = rnd(H, 3 * H), rnd(H, H), rnd(H, F), rnd(F, H)
     b3, b1, bf = torch.randn(3 * H, device=dev), torch.randn(H, device=dev), torch.randn(F, device=dev)
