@@ -141,11 +141,11 @@ def _worker_missing_grad(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _spawn(target, extra=()):
+def _spawn(target, extra=(), world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, 2, port, *extra, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, *extra, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -355,7 +355,7 @@ def _worker_sharded_optimizer(rank, world, port, out):
     from tav_amd.ddp import BucketedAllReduce, GraphedStep
     Cpu = _cpu_sharded_class()
     torch.manual_seed(0)
-    xs = torch.randn(4, 8, 8, generator=torch.Generator().manual_seed(5))
+    xs = torch.randn(4, 4 * world, 8, generator=torch.Generator().manual_seed(5))      # [step, global batch = 4 rows per rank, features]
 
     def build():
         bs = torch.nn.ModuleList([_Branch("a", 12), _Branch("b", 6), _Branch("c", 2)])
@@ -397,6 +397,7 @@ def _worker_sharded_optimizer(rank, world, port, out):
         rgs.run()
         sgs.run()
     same = all(torch.equal(a, b) for a, b in zip(rp, sp))
+    worst = max((a.detach() - b.detach()).abs().max().item() for a, b in zip(rp, sp))
     norms_same = all(torch.equal(a, b) for a, b in zip(rst.norms, sst.norms))
     own, tot = sst.opt.owned_elements()
     # checkpoint: the gathered state equals the replicated optimizer's, and a fresh sharded optimizer loaded from it continues identically
@@ -410,7 +411,9 @@ def _worker_sharded_optimizer(rank, world, port, out):
     resumed_same = all(torch.equal(a, b) for a, b in zip(rp, sp))
     cuts = {b: c for b, (_, _, c) in sst.opt.buckets.items()}
     gathered = [None] * world
-    dist.all_gather_object(gathered, (same, norms_same, sd_same, resumed_same, own, tot, cuts, [n.item() for n in sst.norms], sgs.describe()))
+    worst = max(worst, max((a.detach() - b.detach()).abs().max().item() for a, b in zip(rp, sp)))
+    empty = sum(1 for c in cuts.values() if c[rank + 1] == c[rank])       # buckets in which this rank owns nothing
+    dist.all_gather_object(gathered, (same, norms_same, sd_same, resumed_same, own, tot, cuts, [n.item() for n in sst.norms], sgs.describe(), worst, empty))
     if rank == 0:
         out.put(gathered)
     dist.destroy_process_group()
@@ -421,13 +424,28 @@ def test_sharded_optimizer_two_ranks_bit_equal_to_replicated():
     all-reduce chain: parameters, gradient norms and the gathered optimizer state bit-equal on both ranks over three steps, and over a fourth
     after a load_state_dict into the sharded optimizer."""
     got = _spawn(_worker_sharded_optimizer)
-    for same, norms_same, sd_same, resumed_same, own, tot, cuts, norms, desc in got:
+    for same, norms_same, sd_same, resumed_same, own, tot, cuts, norms, desc, worst, empty in got:
         assert same and norms_same and sd_same and resumed_same, (same, norms_same, sd_same, resumed_same)
         assert all(n > 0.05 for n in norms), norms                 # the clip was active: the exchanged norm mattered
         assert "SHARDED optimizer" in desc
     (own0, tot0), (own1, tot1) = (got[0][4], got[0][5]), (got[1][4], got[1][5])
     assert tot0 == tot1 and own0 + own1 == tot0 and 0.3 < own0 / tot0 < 0.7      # disjoint, complete, roughly balanced
     assert got[0][6] == got[1][6]                                   # both ranks cut the buckets at the same places
+
+
+def test_sharded_optimizer_three_ranks_uneven_ownership():
+    """Three ranks: slices of whole chunks leave the last rank short (or with nothing) in the small buckets.  The f32 sum of three gradients depends on
+    the order the backend adds them in (reduce-to-owner vs all-reduce), so against the replicated optimizer the parameters agree to rounding, not bit
+    for bit (with two ranks they do: the test above); ownership stays disjoint and complete, every rank cuts alike and ends with the same parameters."""
+    got = _spawn(_worker_sharded_optimizer, world=3)
+    assert len(got) == 3
+    for same, norms_same, sd_same, resumed_same, own, tot, cuts, norms, desc, worst, empty in got:
+        assert worst < 1e-5, worst
+        assert all(n > 0.05 for n in norms)
+    assert sum(g[4] for g in got) == got[0][5] and len({g[5] for g in got}) == 1
+    assert got[0][6] == got[1][6] == got[2][6]
+    assert all(abs(a - b) < 1e-6 * max(abs(a), 1e-6) for g in got[1:] for a, b in zip(got[0][7], g[7]))      # one norm on all ranks
+    assert any(g[10] > 0 for g in got) or min(g[4] for g in got) < max(g[4] for g in got)                    # ownership really was uneven
 
 
 def test_shard_cuts_are_equal_whole_chunk_slices():
