@@ -148,10 +148,16 @@ def _spawn(target, extra=(), world=2):
     procs = [ctx.Process(target=target, args=(r, world, port, *extra, q)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    return q.get(timeout=10)
+    try:
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+        return q.get(timeout=10)
+    finally:
+        for p in procs:                       # (a rank that hangs must not outlive the test: these exact children, nothing else)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
 
 
 def test_manual_mode_two_ranks():

@@ -1123,10 +1123,16 @@ def test_sharded_optimizer_two_ranks_one_gpu(gpu, use_graphs):
     procs = [ctx.Process(target=_worker_sharded_step, args=(r, 2, port, use_graphs, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(420)
-        assert p.exitcode == 0
-    got = q.get(timeout=10)
+    try:
+        for p in procs:
+            p.join(420)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+        got = q.get(timeout=10)
+    finally:
+        for p in procs:                       # (a rank that hangs must not outlive the test: these exact children, nothing else)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
     print("sharded optimizer:", got[0]["desc"], "| worst", [g["worst"] for g in got], "| norms", got[0]["norms"], "| moved", got[0]["moved"])
     for g in got:
         assert g["same"] and g["sd_same"], g["worst"]
